@@ -1,0 +1,28 @@
+# Top-level build: everything lands in-tree so that gpurun ships the binaries.
+#   raytracer_amd/librt_hip.so   HIP kernels + C ABI (include/rt.h), gfx950 only
+#   raytracer_amd/librt_host.so  host helper (include/rt_host.h)
+#   oracle/librt_oracle.so       CPU restatement (test infrastructure)
+#   oracle/_ref/*                the reference itself, when /root/reference exists
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX   ?= g++
+PKG   := raytracer_amd
+HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off \
+           -fno-gpu-rdc -Iinclude -Wall -Wno-unused-function
+
+all: host hip oracle
+
+host: $(PKG)/librt_host.so
+$(PKG)/librt_host.so: $(PKG)/host/rt_host.cpp $(PKG)/host/rt_scene_store.hpp include/rt.h include/rt_host.h
+	$(CXX) -std=c++17 -O2 -fPIC -shared -ffp-contract=off -fno-trapping-math -fno-math-errno \
+	    -Iinclude -I$(PKG)/host -o $@ $(PKG)/host/rt_host.cpp
+
+hip: $(PKG)/librt_hip.so
+$(PKG)/librt_hip.so: $(wildcard $(PKG)/csrc/*.hip $(PKG)/csrc/*.h) include/rt.h
+	$(HIPCC) $(HIPFLAGS) -I$(PKG)/csrc -o $@ $(PKG)/csrc/rt_hip.hip
+
+oracle:
+	$(MAKE) -C oracle all
+
+clean:
+	rm -f $(PKG)/*.so oracle/*.so
+.PHONY: all host hip oracle clean

@@ -1,0 +1,294 @@
+/*
+ * rt.h — C ABI of the MI355X-native per-pixel ray/scene intersection path.
+ *
+ * This is the drop-in boundary for fatih-ozdal/Raytracer's pixel loop
+ * (reference raytracer.cpp:40-87).  The reference has no FFI of its own: the
+ * hot path is called from exactly one place, the OpenMP loop body in main().
+ * A maintainer keeps parser::loadFromJson / BuildAllMeshBVHs / BuildTopLevelBVH
+ * (raytracer.cpp:22-26) and stbi_write_png (raytracer.cpp:89) as they are,
+ * flattens `Scene` + the BVH globals (raytracer.cpp:8-11, Bvh.h:76) into an
+ * rt_scene_desc, and replaces the loop with rt_upload_scene + rt_render_tile.
+ * The flatten step is raytracer_amd/host/rt_flatten.hpp; INTEGRATION.md shows
+ * the replacement main().
+ *
+ * Conventions
+ *   - plain C, POD structs, pointers + counts; all floats are IEEE binary32,
+ *     all ids in the scene are 1-based exactly as in the reference
+ *     (vertex_data[i-1], materials[id-1]).
+ *   - every function returns 0 (RT_OK) or a negative rt_status; nothing throws
+ *     or aborts across the boundary; rt_last_error() gives a thread-local
+ *     message (the reference's only status convention is main() returning
+ *     -1/0, raytracer.cpp:15-18,93).
+ *   - caller owns all input arrays; rt_upload_scene copies and retains nothing.
+ *   - there is NO CPU fallback in librt_hip.so: without a HIP device every
+ *     entry point fails with RT_ERR_NO_DEVICE.
+ */
+#ifndef RT_H
+#define RT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+typedef enum rt_status {
+    RT_OK               =  0,
+    RT_ERR_INVALID      = -1,  /* bad argument / inconsistent scene arrays       */
+    RT_ERR_NO_DEVICE    = -2,  /* no HIP device or device index out of range     */
+    RT_ERR_HIP          = -3,  /* a HIP runtime call failed (message has detail) */
+    RT_ERR_OOM          = -4,  /* device allocation failed                       */
+    RT_ERR_UNSUPPORTED  = -5,  /* scene feature outside the built scope          */
+    RT_ERR_OVERFLOW     = -6,  /* ray pool / traversal stack limit exceeded      */
+    RT_ERR_IO           = -7
+} rt_status;
+
+/* PrimKind, HitRecord.h:7-13 */
+enum { RT_KIND_MESH = 0, RT_KIND_TRIANGLE = 1, RT_KIND_SPHERE = 2, RT_KIND_PLANE = 3 };
+/* MaterialType, parser.h:57-63 */
+enum { RT_MAT_NONE = 0, RT_MAT_MIRROR = 1, RT_MAT_CONDUCTOR = 2, RT_MAT_DIELECTRIC = 3 };
+
+/* object flags (Mesh/Triangle/Sphere: parser.h:92-168) */
+enum {
+    RT_OBJ_HAS_TRANSFORM   = 1u << 0,   /* hasTransform                    */
+    RT_OBJ_HAS_MOTION_BLUR = 1u << 1,   /* has_motion_blur                 */
+    RT_OBJ_SMOOTH          = 1u << 2    /* Mesh::is_smooth                 */
+};
+
+/* ------------------------------------------------------ flattened scene POD */
+
+/* BVHNode, Bvh.h:39-49 (32 B).  prim_count > 0 : leaf, left_or_first = first
+ * index into the prim-index array; prim_count == 0 : interior, children are
+ * left_or_first and left_or_first + 1 (raytracer.cpp:749-750). */
+typedef struct rt_bvh_node {
+    float   bmin[3];
+    float   bmax[3];
+    int32_t left_or_first;
+    int32_t prim_count;
+} rt_bvh_node;
+
+/* TopPrim{kind,index}, Bvh.h:6-15 (bounds/centroid are build-only) */
+typedef struct rt_top_prim {
+    uint32_t kind;    /* RT_KIND_MESH / _TRIANGLE / _SPHERE */
+    uint32_t index;   /* index into meshes / triangles / spheres */
+} rt_top_prim;
+
+/* Vertex, parser.h:79-83 */
+typedef struct rt_vertex {
+    float pos[3];
+    float normal[3];
+} rt_vertex;
+
+/* Face, parser.h:85-90 */
+typedef struct rt_face {
+    int32_t i0, i1, i2;   /* 1-based into vertex_data */
+    float   n_unit[3];
+    float   plane_d;
+} rt_face;
+
+/* One MeshBVH (Bvh.h:62-73) together with the face array of the ORIGINAL mesh
+ * it was built for (instances copy that vector, parser.cpp:725).  Offsets index
+ * the concatenated arrays in rt_scene_desc. */
+typedef struct rt_mesh_bvh {
+    uint32_t node_offset;   /* into mesh_nodes; root is node_offset + 0          */
+    uint32_t node_count;    /* nodesUsed                                         */
+    uint32_t prim_offset;   /* into mesh_prim_face                               */
+    uint32_t prim_count;    /* number of triangles                               */
+    uint32_t face_offset;   /* into faces                                        */
+    uint32_t face_count;
+} rt_mesh_bvh;
+
+/* Mesh, parser.h:92-121 — one per scene.meshes entry, instances included. */
+typedef struct rt_mesh {
+    int32_t  bvh_index;       /* Mesh::bvhIndex                                   */
+    int32_t  material_id;     /* 1-based                                          */
+    uint32_t flags;           /* RT_OBJ_*                                         */
+    float    transform[16];   /* Mat4f row-major m[r][c]                          */
+    float    inv_transform[16];
+    float    motion_blur[3];
+} rt_mesh;
+
+/* Triangle, parser.h:123-144 */
+typedef struct rt_triangle {
+    int32_t  material_id;
+    rt_face  face;
+    uint32_t flags;
+    float    transform[16];
+    float    inv_transform[16];
+    float    motion_blur[3];
+} rt_triangle;
+
+/* Sphere, parser.h:146-168 */
+typedef struct rt_sphere {
+    int32_t  material_id;
+    int32_t  center_vertex_id;  /* 1-based */
+    float    radius;
+    uint32_t flags;
+    float    transform[16];
+    float    inv_transform[16];
+    float    motion_blur[3];
+} rt_sphere;
+
+/* Plane, parser.h:170-190 (transform already baked in by parser.cpp:892-903) */
+typedef struct rt_plane {
+    int32_t material_id;
+    float   n_unit[3];
+    float   plane_d;
+} rt_plane;
+
+/* Material, parser.h:65-77 */
+typedef struct rt_material {
+    uint32_t type;              /* RT_MAT_* */
+    float ambient_refl[3];
+    float diffuse_refl[3];
+    float specular_refl[3];
+    float mirror_refl[3];
+    float phong_exponent;
+    float refraction_index;
+    float absorption_index;
+    float absorption_coef[3];
+    float roughness;
+} rt_material;
+
+/* PointLight, parser.h:43-48 */
+typedef struct rt_point_light {
+    float position[3];
+    float intensity[3];
+} rt_point_light;
+
+/* AreaLight, parser.h:50-55 */
+typedef struct rt_area_light {
+    float position[3];
+    float normal[3];
+    float size;
+    float radiance[3];
+} rt_area_light;
+
+/* Scene (parser.h:192-207) + the BVH globals (raytracer.cpp:8-11, Bvh.h:76). */
+typedef struct rt_scene_desc {
+    /* scalars */
+    float    background_color[3];
+    float    ambient_light[3];
+    float    shadow_ray_epsilon;
+    int32_t  max_recursion_depth;
+
+    /* top-level BVH: topBvhNodes[0..nodesUsed), topPrimIdx, topPrims */
+    const rt_bvh_node* top_nodes;      uint32_t n_top_nodes;
+    const uint32_t*    top_prim_idx;   uint32_t n_top_prims;
+    const rt_top_prim* top_prims;      /* n_top_prims entries */
+
+    /* mesh BVHs (concatenated) */
+    const rt_mesh_bvh* mesh_bvhs;      uint32_t n_mesh_bvhs;
+    const rt_bvh_node* mesh_nodes;     uint32_t n_mesh_nodes;
+    /* for leaf slot p of a mesh BVH: faceIdx = prims[primIdx[p]].faceIdx
+     * (raytracer.cpp:783-785), relative to that BVH's face_offset */
+    const uint32_t*    mesh_prim_face; uint32_t n_mesh_prims;
+    const rt_face*     faces;          uint32_t n_faces;
+
+    const rt_vertex*   vertex_data;    uint32_t n_vertices;
+
+    const rt_mesh*     meshes;         uint32_t n_meshes;
+    const rt_triangle* triangles;      uint32_t n_triangles;
+    const rt_sphere*   spheres;        uint32_t n_spheres;
+    const rt_plane*    planes;         uint32_t n_planes;
+
+    const rt_material*    materials;     uint32_t n_materials;
+    const rt_point_light* point_lights;  uint32_t n_point_lights;
+    const rt_area_light*  area_lights;   uint32_t n_area_lights;
+} rt_scene_desc;
+
+/* Camera fields the hot path reads (parser.h:21-41; raytracer.cpp:32-38,343-378).
+ * image_width/height are the FULL image: the per-pixel RNG seed is
+ * i*image_width + j with global i,j (raytracer.cpp:44). */
+typedef struct rt_camera_desc {
+    float   position[3];
+    float   u[3], v[3], w[3];
+    float   q[3];
+    float   pixel_width, pixel_height;
+    int32_t image_width, image_height;
+    int32_t num_samples, samples_per_side;
+    float   aperture_size, focus_distance;
+    int32_t has_depth_of_field;
+} rt_camera_desc;
+
+/* Per-call counters and timings (all optional; zeroed by the callee). */
+typedef struct rt_stats {
+    uint64_t rays_primary;     /* FindClosestHit calls at depth 0               */
+    uint64_t rays_secondary;   /* FindClosestHit calls at depth > 0             */
+    uint64_t rays_shadow;      /* InShadow calls                                */
+    uint64_t records_peak;     /* peak ray-record pool use                      */
+    uint32_t chunks;           /* number of pixel chunks the tile was split in  */
+    uint32_t launches_closest; /* launches of the closest-hit traversal kernel  */
+    uint32_t launches_shadow;
+    float    ms_total;         /* HIP-event time of the whole call on its stream */
+    float    ms_raygen;
+    float    ms_closest;       /* sum over launches of the closest-hit kernel    */
+    float    ms_shade;
+    float    ms_shadow;        /* sum over launches of the any-hit kernel        */
+    float    ms_combine;
+    float    ms_resolve;
+} rt_stats;
+
+typedef struct rt_scene rt_scene;   /* opaque, library-owned, one per GPU */
+
+/* render flags for rt_scene_set_option(RT_OPT_FLAGS) */
+enum {
+    RT_FLAG_TIMING = 1u << 0   /* bracket kernels with HIP events -> rt_stats.ms_* */
+};
+enum {
+    RT_OPT_FLAGS          = 1,  /* bitmask of RT_FLAG_*                            */
+    RT_OPT_POOL_RECORDS   = 2,  /* capacity of the ray-record pool (records)       */
+    RT_OPT_CHUNK_SAMPLES  = 3   /* max pixel-samples started per chunk             */
+};
+
+/* Number of HIP devices visible to this process (<0: rt_status). */
+int rt_device_count(void);
+
+/* Copy the flattened scene to `device` and build the device layout (64-B node
+ * pairs, 48-B leaf-ordered triangle records, per-object transform records).
+ * Replaces nothing in the reference: it is the set-up that precedes the loop
+ * at raytracer.cpp:30.  Synchronous. */
+int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out);
+
+int rt_scene_set_option(rt_scene* s, int option, uint64_t value);
+
+/* Render the pixel rectangle [x0,x0+tile_w) x [y0,y0+tile_h) of camera `cam`
+ * into caller-owned HOST memory.  Replaces the loop body raytracer.cpp:42-86
+ * for those pixels.  rgb_out: row-major RGB8, row 0 = top row of the tile,
+ * rgb_row_stride_bytes between rows (raytracer.cpp:82-85 layout).
+ * hit_id_out (nullable): 2 x u32 per pixel, row-major, tile_w*2 words per row:
+ *   word0 = kind<<28 | object index, word1 = faceIdx inside the mesh (0 for
+ *   other kinds); 0xFFFFFFFF,0xFFFFFFFF = miss.  It is the primary hit of the
+ *   pixel's FIRST sample — the reference never exposes it; it is what
+ *   IntersectTopBVH returns in closestType/index/hitTriFace
+ *   (raytracer.cpp:527-531).
+ * Synchronous on return. */
+int rt_render_tile(rt_scene* s, const rt_camera_desc* cam,
+                   int x0, int y0, int tile_w, int tile_h,
+                   uint8_t* rgb_out, size_t rgb_row_stride_bytes,
+                   uint32_t* hit_id_out, rt_stats* stats);
+
+/* Same, but rgb_out / hit_id_out are DEVICE pointers on the scene's GPU and the
+ * work is enqueued on `hip_stream` (a hipStream_t passed as void*; NULL = the
+ * scene's own stream).  Returns after enqueueing unless stats != NULL or
+ * RT_FLAG_TIMING is set, in which case it synchronises the stream to fill
+ * stats.  Used for multi-GPU frames: every GPU renders its tiles into its own
+ * device framebuffer and only that framebuffer is gathered (xGMI). */
+int rt_render_tile_device(rt_scene* s, const rt_camera_desc* cam,
+                          int x0, int y0, int tile_w, int tile_h,
+                          void* d_rgb_out, size_t rgb_row_stride_bytes,
+                          void* d_hit_id_out, rt_stats* stats, void* hip_stream);
+
+/* Wait for everything enqueued on the scene's stream. */
+int rt_sync(rt_scene* s);
+
+void rt_free_scene(rt_scene* s);
+
+const char* rt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_H */
