@@ -1,0 +1,177 @@
+// rt_device.h — device data layout and FP32 math for the gfx950 ray path.
+//
+// Arithmetic contract: IEEE binary32, compiled with
+// -ffp-contract=off, correctly-rounded divide and sqrt (hipcc default), operation
+// order exactly as in the reference lines cited at each function, so that every
+// intermediate equals the x86-64 (no-FMA) reference value bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rt.h"
+
+#define RT_INF __builtin_huge_valf()
+#define RT_FLT_MAX 3.402823466e+38F   // MathF.h:6
+#define RT_EPS_PARALLEL 1e-8f         // raytracer.h:12
+
+// ------------------------------------------------------------ link encoding
+// A link names the next thing to visit.  bit31 clear: index of a DNode (an
+// interior node of a reference BVH).  bit31 set: a leaf — index of the first
+// DTri (mesh level) or first DTopPrim slot (top level) — or a special value.
+#define RT_LINK_LEAF     0x80000000u
+#define RT_LINK_DONE     0xFFFFFFFFu   // empty stack at the top level / empty BVH
+#define RT_LINK_SENTINEL 0xFFFFFFFEu   // bottom of a mesh traversal's stack segment
+#define RT_LINK_INDEX(l) ((l) & 0x7FFFFFFFu)
+
+// One interior node of a reference BVH (Bvh.h:39-49) holding BOTH children's
+// boxes, so one 64-byte fetch decides both descents.  64-byte aligned.
+//   a = lmin.xyz, lmax.x   b = lmax.yz, rmin.xy   c = rmin.z, rmax.xyz
+struct __attribute__((aligned(64))) DNode {
+    float4   a, b, c;
+    uint32_t llink, rlink, pad0, pad1;
+};
+static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
+
+// Leaf-ordered triangle record: position p of a mesh BVH's primIdx array
+// (raytracer.cpp:783-789 resolved at upload: primIdx -> prims[].faceIdx ->
+// faces[] -> vertex_data[]).  e1 = a-b, e2 = a-c are the first two columns of
+// the Cramer system (raytracer.cpp:902-903), computed once on the host with the
+// same FP32 subtraction.  `remaining` = triangles left in this leaf, this one
+// included.  48 bytes = three 16-byte loads.
+struct __attribute__((aligned(16))) DTri {
+    float ax, ay, az, e1x;
+    float e1y, e1z, e2x, e2y;
+    float e2z;
+    uint32_t face;        // faceIdx inside the mesh's face set
+    uint32_t remaining;
+    uint32_t pad;
+};
+static_assert(sizeof(DTri) == 48, "DTri is 48 bytes");
+
+// Shading-side data of the same triangle slot (only read for the closest hit).
+struct __attribute__((aligned(8))) DTriShade {
+    float nx, ny, nz;     // Face::n_unit
+    int32_t i0, i1, i2;   // 1-based vertex ids (smooth normals)
+};
+
+// Object record shared by mesh instances, spheres and triangles.
+struct __attribute__((aligned(16))) DObject {
+    float    M[16];       // transformation (row-major)
+    float    Minv[16];    // invTransformation
+    float    mbx, mby, mbz;
+    uint32_t flags;       // RT_OBJ_* | DOBJ_*
+    int32_t  material_id;
+    uint32_t root_link;   // mesh: link of the BVH root (RT_LINK_DONE if empty)
+    float    rminx, rminy, rminz, rmaxx, rmaxy, rmaxz;   // mesh: root box
+    // sphere: p0..p3 = centre.xyz, radius.  triangle: a, e1, e2, n_unit in p0..p11
+    float    p[12];
+};
+#define DOBJ_NEG_DET (1u << 8)   // transformation.determinant3x3() < 0 (raytracer.cpp:468,489,505)
+
+// One slot of the top-level leaf order (topPrimIdx, raytracer.cpp:550-551).
+struct DTopPrim {
+    uint32_t kind;        // RT_KIND_*
+    uint32_t index;       // object index inside its kind
+    uint32_t remaining;   // prims left in this leaf, this one included
+    uint32_t obj;         // index into DScene::objects
+};
+
+struct DMaterial {
+    uint32_t type;
+    float ka[3], kd[3], ks[3], km[3];
+    float phong, ior, absorb_index;
+    float absorb_coef[3];
+    float roughness;
+};
+
+struct DPlane { float nx, ny, nz, d; int32_t material_id; };
+struct DPointLight { float px, py, pz, ix, iy, iz; };
+
+struct DScene {
+    const DNode*      nodes;
+    const DTri*       tris;
+    const DTriShade*  tri_shade;
+    const float4*     vnormals;      // vertex normal per vertex_data entry (w unused)
+    const DObject*    objects;
+    const DTopPrim*   top_prims;
+    const DPlane*     planes;
+    const DMaterial*  materials;
+    const DPointLight* point_lights;
+    uint32_t n_planes, n_point_lights, n_materials;
+    uint32_t top_root_link;
+    float    top_rmin[3], top_rmax[3];
+    float    background[3], ambient[3];
+    float    shadow_eps;
+    int32_t  max_depth;
+    uint32_t mesh_obj_base, sphere_obj_base, tri_obj_base;   // objects[] = meshes | spheres | triangles
+};
+
+struct DCamera {
+    float pos[3], u[3], v[3], w[3], q[3];
+    float pixel_w, pixel_h;
+    int32_t image_w, image_h, num_samples, sps;
+    float aperture, focus;
+    int32_t dof;
+};
+
+// ------------------------------------------------------------------- Vec3f.h
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 ldv(const float* p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }   // Vec3f.h:16-18
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {                                                   // Vec3f.h:20-24
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float vlen(V3 a) { return __fsqrt_rn(a.x * a.x + a.y * a.y + a.z * a.z); }   // Vec3f.h:26-28
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 emul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 vdiv(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+
+// MathF.h:18-28
+__device__ __forceinline__ float q_rsqrt(float x) {
+    if (x <= 0.0f) return 0.0f;
+    uint32_t i = __float_as_uint(x);
+    i = 0x5f3759dfu - (i >> 1);
+    float y = __uint_as_float(i);
+    y = y * (1.5f - 0.5f * x * y * y);
+    return y;
+}
+// Vec3f.h:30-39
+__device__ __forceinline__ V3 normalize(V3 a) {
+    float inv = q_rsqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    if (inv == 0.0f) return mk(0.f, 0.f, 0.f);
+    return a * inv;
+}
+// MathF.h:30-38
+__device__ __forceinline__ float det3x3(float a11, float a12, float a13, float a21, float a22, float a23, float a31,
+                                        float a32, float a33) {
+    return a11 * (a22 * a33 - a23 * a32) - a12 * (a21 * a33 - a23 * a31) + a13 * (a21 * a32 - a22 * a31);
+}
+// Mat4f.h:21-27
+__device__ __forceinline__ V3 xf_point(const float* m, V3 p) {
+    float x = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3] * 1;
+    float y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7] * 1;
+    float z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11] * 1;
+    float w = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15] * 1;
+    return mk(x / w, y / w, z / w);
+}
+// Mat4f.h:30-36
+__device__ __forceinline__ V3 xf_vector(const float* m, V3 v) {
+    float x = m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3] * 0;
+    float y = m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7] * 0;
+    float z = m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11] * 0;
+    return mk(x, y, z);
+}
+// transpose().transformVector(v): Mat4f.h:51-59 then 30-36
+__device__ __forceinline__ V3 xf_vector_transposed(const float* m, V3 v) {
+    float x = m[0] * v.x + m[4] * v.y + m[8] * v.z + m[12] * 0;
+    float y = m[1] * v.x + m[5] * v.y + m[9] * v.z + m[13] * 0;
+    float z = m[2] * v.x + m[6] * v.y + m[10] * v.z + m[14] * 0;
+    return mk(x, y, z);
+}
+
+// std::pow(float,float) / std::exp(float) of the reference (raytracer.cpp:1517,
+// 1356-1358).  See DESIGN.md §Numerics for how close OCML is to glibc here.
+__device__ __forceinline__ float rt_powf(float a, float b) { return powf(a, b); }
+__device__ __forceinline__ float rt_expf(float a) { return expf(a); }

@@ -1,0 +1,663 @@
+// rt_hip.hip — C ABI (include/rt.h) of the gfx950 ray path: scene upload
+// (re-layout of the flattened reference scene into the device layout of
+// rt_device.h) and the render driver that enqueues the wavefront pipeline of
+// rt_kernels.h.  Host code here is set-up and launch logic only; there is no
+// CPU rendering path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt.h"
+#include "rt_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                               \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return RT_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        if (need == 0) return RT_OK;
+        HIPCHK(hipMalloc(&p, need));
+        bytes = need;
+        return RT_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+template <class T>
+int upload_vec(DevBuf& b, const std::vector<T>& v) {
+    int rc = b.ensure(std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (rc) return rc;
+    if (!v.empty()) HIPCHK(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+enum TimeCat { TC_RAYGEN, TC_CLOSEST, TC_SHADE, TC_SHADOW, TC_COMBINE, TC_RESOLVE, TC_COUNT };
+
+}  // namespace
+
+struct rt_scene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_cu = 256;
+    int blocks_closest = 0, blocks_shadow = 0;   // persistent grid sizes
+
+    // device scene
+    DevBuf b_nodes, b_tris, b_tri_shade, b_vnormals, b_objects, b_top_prims, b_planes, b_materials, b_lights;
+    DScene ds{};
+    bool has_reflective = false;      // any material with type != None
+    bool needs_sequential_rng = false;   // area lights or rough reflective materials (RNG drawn while shading)
+    uint32_t n_point_lights = 0;
+
+    // work memory
+    Pool pool{};
+    DevBuf b_ray0, b_ray1, b_hit0, b_hit1, b_nrm, b_link, b_color, b_shadow_rec, b_shadow_lit;
+    DevBuf b_ctl, b_spill, b_mt, b_fb, b_hits;
+    Control* h_ctl = nullptr;   // pinned
+
+    // options
+    uint64_t opt_flags = 0;
+    uint64_t opt_pool_records = 16ull << 20;
+    uint64_t opt_chunk_samples = 8ull << 20;
+
+    // timing events
+    struct Ev { hipEvent_t a, b; int cat; };
+    std::vector<Ev> ev_used, ev_free;
+};
+
+namespace {
+
+// ---------------------------------------------------------------- validation
+int validate_bvh(const rt_bvh_node* nodes, uint32_t count, uint32_t n_prims, const char* what) {
+    if (count == 0) return RT_OK;
+    std::vector<uint8_t> covered(n_prims, 0);
+    for (uint32_t i = 0; i < count; i++) {
+        const rt_bvh_node& n = nodes[i];
+        if (n.prim_count > 0) {
+            if (n.left_or_first < 0 || (uint64_t)n.left_or_first + (uint64_t)n.prim_count > n_prims)
+                return fail(RT_ERR_INVALID, "%s: leaf %u range out of bounds", what, i);
+        } else if (n.prim_count == 0) {
+            // children are allocated after their parent (raytracer.cpp:189-190, 323-324): enforcing it
+            // guarantees the device traversal terminates
+            if (n.left_or_first <= (int32_t)i || (uint32_t)n.left_or_first + 1 >= count)
+                return fail(RT_ERR_INVALID, "%s: interior node %u has bad children", what, i);
+        } else {
+            return fail(RT_ERR_INVALID, "%s: node %u has negative prim_count", what, i);
+        }
+    }
+    return RT_OK;
+}
+
+int validate_scene(const rt_scene_desc* s) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is NULL");
+    if (s->n_materials == 0) return fail(RT_ERR_INVALID, "scene has no materials");
+    auto mat_ok = [&](int32_t id) { return id >= 1 && (uint32_t)id <= s->n_materials; };
+    auto vtx_ok = [&](int32_t id) { return id >= 1 && (uint32_t)id <= s->n_vertices; };
+    int rc = validate_bvh(s->top_nodes, s->n_top_nodes, s->n_top_prims, "top BVH");
+    if (rc) return rc;
+    for (uint32_t i = 0; i < s->n_top_prims; i++) {
+        if (s->top_prim_idx[i] >= s->n_top_prims) return fail(RT_ERR_INVALID, "top_prim_idx[%u] out of range", i);
+        const rt_top_prim& p = s->top_prims[i];
+        uint32_t lim = p.kind == RT_KIND_MESH ? s->n_meshes : p.kind == RT_KIND_SPHERE ? s->n_spheres
+                     : p.kind == RT_KIND_TRIANGLE ? s->n_triangles : 0;
+        if (p.index >= lim) return fail(RT_ERR_INVALID, "top prim %u: bad kind/index", i);
+    }
+    for (uint32_t b = 0; b < s->n_mesh_bvhs; b++) {
+        const rt_mesh_bvh& mb = s->mesh_bvhs[b];
+        if ((uint64_t)mb.node_offset + mb.node_count > s->n_mesh_nodes || (uint64_t)mb.prim_offset + mb.prim_count > s->n_mesh_prims ||
+            (uint64_t)mb.face_offset + mb.face_count > s->n_faces)
+            return fail(RT_ERR_INVALID, "mesh BVH %u: offsets out of range", b);
+        rc = validate_bvh(s->mesh_nodes + mb.node_offset, mb.node_count, mb.prim_count, "mesh BVH");
+        if (rc) return rc;
+        for (uint32_t p = 0; p < mb.prim_count; p++)
+            if (s->mesh_prim_face[mb.prim_offset + p] >= mb.face_count) return fail(RT_ERR_INVALID, "mesh BVH %u: face index out of range", b);
+        for (uint32_t f = 0; f < mb.face_count; f++) {
+            const rt_face& fc = s->faces[mb.face_offset + f];
+            if (!vtx_ok(fc.i0) || !vtx_ok(fc.i1) || !vtx_ok(fc.i2)) return fail(RT_ERR_INVALID, "face %u: vertex id out of range", f);
+        }
+    }
+    for (uint32_t i = 0; i < s->n_meshes; i++) {
+        const rt_mesh& m = s->meshes[i];
+        if (m.bvh_index < 0 || (uint32_t)m.bvh_index >= s->n_mesh_bvhs) return fail(RT_ERR_INVALID, "mesh %u: bad bvh_index", i);
+        if (!mat_ok(m.material_id)) return fail(RT_ERR_INVALID, "mesh %u: bad material id", i);
+    }
+    for (uint32_t i = 0; i < s->n_triangles; i++) {
+        const rt_triangle& t = s->triangles[i];
+        if (!mat_ok(t.material_id) || !vtx_ok(t.face.i0) || !vtx_ok(t.face.i1) || !vtx_ok(t.face.i2))
+            return fail(RT_ERR_INVALID, "triangle %u: bad ids", i);
+    }
+    for (uint32_t i = 0; i < s->n_spheres; i++)
+        if (!mat_ok(s->spheres[i].material_id) || !vtx_ok(s->spheres[i].center_vertex_id)) return fail(RT_ERR_INVALID, "sphere %u: bad ids", i);
+    for (uint32_t i = 0; i < s->n_planes; i++)
+        if (!mat_ok(s->planes[i].material_id)) return fail(RT_ERR_INVALID, "plane %u: bad material id", i);
+    return RT_OK;
+}
+
+// Mat4f::determinant3x3, Mat4f.h:126-130
+float mat_det3(const float* m) {
+    return m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+}
+
+// Re-layout of one reference BVH: every interior node becomes a DNode carrying
+// both children's boxes; leaves become links into the leaf-ordered prim array.
+struct BvhLayout {
+    uint32_t root_link = RT_LINK_DONE;
+    float rmin[3] = {0, 0, 0}, rmax[3] = {0, 0, 0};
+};
+BvhLayout layout_bvh(const rt_bvh_node* nodes, uint32_t count, uint32_t leaf_base, std::vector<DNode>& out) {
+    BvhLayout L;
+    if (count == 0) return L;
+    std::vector<uint32_t> slot(count, 0);
+    uint32_t base = (uint32_t)out.size(), n_int = 0;
+    for (uint32_t i = 0; i < count; i++)
+        if (nodes[i].prim_count == 0) slot[i] = base + n_int++;
+    auto link_of = [&](uint32_t i) -> uint32_t {
+        return nodes[i].prim_count > 0 ? (RT_LINK_LEAF | (leaf_base + (uint32_t)nodes[i].left_or_first)) : slot[i];
+    };
+    out.resize(base + n_int);
+    for (uint32_t i = 0; i < count; i++) {
+        if (nodes[i].prim_count != 0) continue;
+        const rt_bvh_node& l = nodes[nodes[i].left_or_first];
+        const rt_bvh_node& r = nodes[nodes[i].left_or_first + 1];
+        DNode& d = out[slot[i]];
+        d.a = make_float4(l.bmin[0], l.bmin[1], l.bmin[2], l.bmax[0]);
+        d.b = make_float4(l.bmax[1], l.bmax[2], r.bmin[0], r.bmin[1]);
+        d.c = make_float4(r.bmin[2], r.bmax[0], r.bmax[1], r.bmax[2]);
+        d.llink = link_of((uint32_t)nodes[i].left_or_first);
+        d.rlink = link_of((uint32_t)nodes[i].left_or_first + 1);
+        d.pad0 = d.pad1 = 0;
+    }
+    L.root_link = link_of(0);
+    std::memcpy(L.rmin, nodes[0].bmin, 12);
+    std::memcpy(L.rmax, nodes[0].bmax, 12);
+    return L;
+}
+
+void fill_object_common(DObject& o, uint32_t flags, const float* M, const float* Minv, const float* mb, int material_id) {
+    std::memset(&o, 0, sizeof(o));
+    std::memcpy(o.M, M, 64);
+    std::memcpy(o.Minv, Minv, 64);
+    o.mbx = mb[0]; o.mby = mb[1]; o.mbz = mb[2];
+    o.flags = flags & (RT_OBJ_HAS_TRANSFORM | RT_OBJ_HAS_MOTION_BLUR | RT_OBJ_SMOOTH);
+    if ((flags & RT_OBJ_HAS_TRANSFORM) && mat_det3(M) < 0.0f) o.flags |= DOBJ_NEG_DET;
+    o.material_id = material_id;
+    o.root_link = RT_LINK_DONE;
+}
+
+int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
+    std::vector<DNode> nodes;
+    std::vector<DTri> tris(s->n_mesh_prims);
+    std::vector<DTriShade> tshade(s->n_mesh_prims);
+
+    // mesh BVHs
+    std::vector<BvhLayout> mesh_layout(s->n_mesh_bvhs);
+    for (uint32_t b = 0; b < s->n_mesh_bvhs; b++) {
+        const rt_mesh_bvh& mb = s->mesh_bvhs[b];
+        mesh_layout[b] = layout_bvh(s->mesh_nodes + mb.node_offset, mb.node_count, mb.prim_offset, nodes);
+        for (uint32_t p = 0; p < mb.prim_count; p++) {
+            const uint32_t fi = s->mesh_prim_face[mb.prim_offset + p];
+            const rt_face& f = s->faces[mb.face_offset + fi];
+            const float* a = s->vertex_data[f.i0 - 1].pos;
+            const float* bb = s->vertex_data[f.i1 - 1].pos;
+            const float* c = s->vertex_data[f.i2 - 1].pos;
+            DTri& t = tris[mb.prim_offset + p];
+            t.ax = a[0]; t.ay = a[1]; t.az = a[2];
+            t.e1x = a[0] - bb[0]; t.e1y = a[1] - bb[1]; t.e1z = a[2] - bb[2];   // col_A0, raytracer.cpp:902
+            t.e2x = a[0] - c[0];  t.e2y = a[1] - c[1];  t.e2z = a[2] - c[2];    // col_A1, raytracer.cpp:903
+            t.face = fi;
+            t.remaining = 1;
+            t.pad = 0;
+            DTriShade& ts = tshade[mb.prim_offset + p];
+            ts.nx = f.n_unit[0]; ts.ny = f.n_unit[1]; ts.nz = f.n_unit[2];
+            ts.i0 = f.i0; ts.i1 = f.i1; ts.i2 = f.i2;
+        }
+        for (uint32_t i = 0; i < mb.node_count; i++) {
+            const rt_bvh_node& n = s->mesh_nodes[mb.node_offset + i];
+            for (int32_t k = 0; k < n.prim_count; k++) tris[mb.prim_offset + n.left_or_first + k].remaining = (uint32_t)(n.prim_count - k);
+        }
+    }
+
+    // objects: meshes | spheres | triangles
+    std::vector<DObject> objects(s->n_meshes + s->n_spheres + s->n_triangles);
+    sc->ds.mesh_obj_base = 0;
+    sc->ds.sphere_obj_base = s->n_meshes;
+    sc->ds.tri_obj_base = s->n_meshes + s->n_spheres;
+    for (uint32_t i = 0; i < s->n_meshes; i++) {
+        const rt_mesh& m = s->meshes[i];
+        DObject& o = objects[i];
+        fill_object_common(o, m.flags, m.transform, m.inv_transform, m.motion_blur, m.material_id);
+        const BvhLayout& L = mesh_layout[m.bvh_index];
+        o.root_link = L.root_link;
+        o.rminx = L.rmin[0]; o.rminy = L.rmin[1]; o.rminz = L.rmin[2];
+        o.rmaxx = L.rmax[0]; o.rmaxy = L.rmax[1]; o.rmaxz = L.rmax[2];
+    }
+    for (uint32_t i = 0; i < s->n_spheres; i++) {
+        const rt_sphere& sp = s->spheres[i];
+        DObject& o = objects[sc->ds.sphere_obj_base + i];
+        fill_object_common(o, sp.flags, sp.transform, sp.inv_transform, sp.motion_blur, sp.material_id);
+        const float* c = s->vertex_data[sp.center_vertex_id - 1].pos;
+        o.p[0] = c[0]; o.p[1] = c[1]; o.p[2] = c[2]; o.p[3] = sp.radius;
+    }
+    for (uint32_t i = 0; i < s->n_triangles; i++) {
+        const rt_triangle& t = s->triangles[i];
+        DObject& o = objects[sc->ds.tri_obj_base + i];
+        fill_object_common(o, t.flags, t.transform, t.inv_transform, t.motion_blur, t.material_id);
+        const float* a = s->vertex_data[t.face.i0 - 1].pos;
+        const float* b = s->vertex_data[t.face.i1 - 1].pos;
+        const float* c = s->vertex_data[t.face.i2 - 1].pos;
+        o.p[0] = a[0]; o.p[1] = a[1]; o.p[2] = a[2];
+        o.p[3] = a[0] - b[0]; o.p[4] = a[1] - b[1]; o.p[5] = a[2] - b[2];
+        o.p[6] = a[0] - c[0]; o.p[7] = a[1] - c[1]; o.p[8] = a[2] - c[2];
+        o.p[9] = t.face.n_unit[0]; o.p[10] = t.face.n_unit[1]; o.p[11] = t.face.n_unit[2];
+    }
+
+    // top level: slots in topPrimIdx order
+    std::vector<DTopPrim> top(s->n_top_prims);
+    for (uint32_t k = 0; k < s->n_top_prims; k++) {
+        const rt_top_prim& p = s->top_prims[s->top_prim_idx[k]];
+        top[k].kind = p.kind;
+        top[k].index = p.index;
+        top[k].remaining = 1;
+        top[k].obj = p.kind == RT_KIND_MESH ? sc->ds.mesh_obj_base + p.index
+                   : p.kind == RT_KIND_SPHERE ? sc->ds.sphere_obj_base + p.index : sc->ds.tri_obj_base + p.index;
+    }
+    for (uint32_t i = 0; i < s->n_top_nodes; i++) {
+        const rt_bvh_node& n = s->top_nodes[i];
+        for (int32_t k = 0; k < n.prim_count; k++) top[n.left_or_first + k].remaining = (uint32_t)(n.prim_count - k);
+    }
+    BvhLayout TL = layout_bvh(s->top_nodes, s->n_top_prims ? s->n_top_nodes : 0, 0, nodes);
+    if (nodes.size() >= 0x7FFFFFF0u || tris.size() >= 0x7FFFFFF0u) return fail(RT_ERR_UNSUPPORTED, "scene too large for 31-bit links");
+
+    std::vector<float4> vn(s->n_vertices);
+    for (uint32_t i = 0; i < s->n_vertices; i++)
+        vn[i] = make_float4(s->vertex_data[i].normal[0], s->vertex_data[i].normal[1], s->vertex_data[i].normal[2], 0.f);
+
+    std::vector<DPlane> planes(s->n_planes);
+    for (uint32_t i = 0; i < s->n_planes; i++) {
+        planes[i].nx = s->planes[i].n_unit[0]; planes[i].ny = s->planes[i].n_unit[1]; planes[i].nz = s->planes[i].n_unit[2];
+        planes[i].d = s->planes[i].plane_d;
+        planes[i].material_id = s->planes[i].material_id;
+    }
+    std::vector<DMaterial> mats(s->n_materials);
+    sc->has_reflective = false;
+    sc->needs_sequential_rng = s->n_area_lights > 0;
+    for (uint32_t i = 0; i < s->n_materials; i++) {
+        const rt_material& m = s->materials[i];
+        DMaterial& d = mats[i];
+        d.type = m.type;
+        std::memcpy(d.ka, m.ambient_refl, 12); std::memcpy(d.kd, m.diffuse_refl, 12);
+        std::memcpy(d.ks, m.specular_refl, 12); std::memcpy(d.km, m.mirror_refl, 12);
+        d.phong = m.phong_exponent; d.ior = m.refraction_index; d.absorb_index = m.absorption_index;
+        std::memcpy(d.absorb_coef, m.absorption_coef, 12);
+        d.roughness = m.roughness;
+        if (m.type != RT_MAT_NONE) {
+            sc->has_reflective = true;
+            if (m.roughness > 0.0f) sc->needs_sequential_rng = true;   // PerturbReflection draws (raytracer.cpp:1441-1452)
+        }
+    }
+    std::vector<DPointLight> lights(s->n_point_lights);
+    for (uint32_t i = 0; i < s->n_point_lights; i++) {
+        lights[i].px = s->point_lights[i].position[0]; lights[i].py = s->point_lights[i].position[1]; lights[i].pz = s->point_lights[i].position[2];
+        lights[i].ix = s->point_lights[i].intensity[0]; lights[i].iy = s->point_lights[i].intensity[1]; lights[i].iz = s->point_lights[i].intensity[2];
+    }
+
+    int rc;
+    if ((rc = upload_vec(sc->b_nodes, nodes)) || (rc = upload_vec(sc->b_tris, tris)) || (rc = upload_vec(sc->b_tri_shade, tshade)) ||
+        (rc = upload_vec(sc->b_vnormals, vn)) || (rc = upload_vec(sc->b_objects, objects)) || (rc = upload_vec(sc->b_top_prims, top)) ||
+        (rc = upload_vec(sc->b_planes, planes)) || (rc = upload_vec(sc->b_materials, mats)) || (rc = upload_vec(sc->b_lights, lights)))
+        return rc;
+
+    DScene& D = sc->ds;
+    D.nodes = (const DNode*)sc->b_nodes.p;
+    D.tris = (const DTri*)sc->b_tris.p;
+    D.tri_shade = (const DTriShade*)sc->b_tri_shade.p;
+    D.vnormals = (const float4*)sc->b_vnormals.p;
+    D.objects = (const DObject*)sc->b_objects.p;
+    D.top_prims = (const DTopPrim*)sc->b_top_prims.p;
+    D.planes = (const DPlane*)sc->b_planes.p;
+    D.materials = (const DMaterial*)sc->b_materials.p;
+    D.point_lights = (const DPointLight*)sc->b_lights.p;
+    D.n_planes = s->n_planes;
+    D.n_point_lights = s->n_point_lights;
+    D.n_materials = s->n_materials;
+    D.top_root_link = TL.root_link;
+    std::memcpy(D.top_rmin, TL.rmin, 12);
+    std::memcpy(D.top_rmax, TL.rmax, 12);
+    std::memcpy(D.background, s->background_color, 12);
+    std::memcpy(D.ambient, s->ambient_light, 12);
+    D.shadow_eps = s->shadow_ray_epsilon;
+    D.max_depth = s->max_recursion_depth;
+    sc->n_point_lights = s->n_point_lights;
+    return RT_OK;
+}
+
+int ensure_pool(rt_scene* sc) {
+    const size_t cap = (size_t)sc->opt_pool_records;
+    if (sc->pool.cap_records == cap && sc->b_ray0.p) return RT_OK;
+    const size_t lights = std::max<uint32_t>(sc->n_point_lights, 1);
+    const size_t cap_sh = cap * std::min<size_t>(lights, 4);
+    int rc;
+    if ((rc = sc->b_ray0.ensure(cap * 16)) || (rc = sc->b_ray1.ensure(cap * 16)) || (rc = sc->b_hit0.ensure(cap * 16)) ||
+        (rc = sc->b_hit1.ensure(cap * 8)) || (rc = sc->b_nrm.ensure(cap * 16)) || (rc = sc->b_link.ensure(cap * 16)) ||
+        (rc = sc->b_color.ensure(cap * 16)) || (rc = sc->b_shadow_rec.ensure(cap_sh * 4)) || (rc = sc->b_shadow_lit.ensure(cap_sh)))
+        return rc;
+    Pool& P = sc->pool;
+    P.ray0 = (float4*)sc->b_ray0.p; P.ray1 = (float4*)sc->b_ray1.p; P.hit0 = (uint4*)sc->b_hit0.p; P.hit1 = (float2*)sc->b_hit1.p;
+    P.nrm = (float4*)sc->b_nrm.p; P.link = (uint4*)sc->b_link.p; P.color = (float4*)sc->b_color.p;
+    P.shadow_rec = (uint32_t*)sc->b_shadow_rec.p; P.shadow_lit = (uint8_t*)sc->b_shadow_lit.p;
+    P.cap_records = (uint32_t)cap;
+    P.cap_shadow = (uint32_t)cap_sh;
+    return RT_OK;
+}
+
+struct Timer {
+    rt_scene* sc;
+    hipStream_t st;
+    bool on;
+    int begin(int cat) {
+        if (!on) return RT_OK;
+        rt_scene::Ev e;
+        if (!sc->ev_free.empty()) { e = sc->ev_free.back(); sc->ev_free.pop_back(); }
+        else { HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); }
+        e.cat = cat;
+        HIPCHK(hipEventRecord(e.a, st));
+        sc->ev_used.push_back(e);
+        return RT_OK;
+    }
+    int end() {
+        if (!on) return RT_OK;
+        HIPCHK(hipEventRecord(sc->ev_used.back().b, st));
+        return RT_OK;
+    }
+};
+
+void to_dcamera(const rt_camera_desc* c, DCamera& d) {
+    std::memcpy(d.pos, c->position, 12); std::memcpy(d.u, c->u, 12); std::memcpy(d.v, c->v, 12);
+    std::memcpy(d.w, c->w, 12); std::memcpy(d.q, c->q, 12);
+    d.pixel_w = c->pixel_width; d.pixel_h = c->pixel_height;
+    d.image_w = c->image_width; d.image_h = c->image_height;
+    d.num_samples = c->num_samples; d.sps = c->samples_per_side;
+    d.aperture = c->aperture_size; d.focus = c->focus_distance;
+    d.dof = c->has_depth_of_field;
+}
+
+int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, int h, uint8_t* d_rgb, size_t stride,
+                uint32_t* d_hits, rt_stats* stats, hipStream_t st) {
+    if (!sc || !cam) return fail(RT_ERR_INVALID, "NULL scene or camera");
+    if (w <= 0 || h <= 0 || x0 < 0 || y0 < 0 || x0 + w > cam->image_width || y0 + h > cam->image_height)
+        return fail(RT_ERR_INVALID, "tile [%d,%d %dx%d] outside the %dx%d image", x0, y0, w, h, cam->image_width, cam->image_height);
+    if (!d_rgb || stride < (size_t)w * 3) return fail(RT_ERR_INVALID, "bad output buffer / stride");
+    const int N = cam->num_samples, sps = cam->samples_per_side;
+    if (N < 1 || sps < 1 || N > 65535) return fail(RT_ERR_INVALID, "num_samples %d / samples_per_side %d not supported", N, sps);
+    if (sc->needs_sequential_rng)
+        return fail(RT_ERR_UNSUPPORTED, "scene draws random numbers while shading (area lights or Roughness > 0): "
+                                        "not built yet (SURVEY §8f-1)");
+    int depth = sc->ds.max_depth;
+    if (depth >= RT_MAX_GEN) return fail(RT_ERR_UNSUPPORTED, "MaxRecursionDepth %d exceeds %d", depth, RT_MAX_GEN - 1);
+    HIPCHK(hipSetDevice(sc->device));
+    if (depth < 0) {   // ComputeColor returns (0,0,0) for every primary ray (raytracer.cpp:384-386)
+        HIPCHK(hipMemset2DAsync(d_rgb, stride, 0, (size_t)w * 3, h, st));
+        if (d_hits) HIPCHK(hipMemsetAsync(d_hits, 0xFF, (size_t)w * h * 8, st));
+        if (stats) { std::memset(stats, 0, sizeof(*stats)); HIPCHK(hipStreamSynchronize(st)); }
+        return RT_OK;
+    }
+    const int D = sc->has_reflective ? depth : 0;   // without reflective materials no child ray is ever spawned
+    int rc = ensure_pool(sc);
+    if (rc) return rc;
+    if ((rc = sc->b_ctl.ensure(sizeof(Control)))) return rc;
+    Control* ctl = (Control*)sc->b_ctl.p;
+    const size_t spill_per_block = (size_t)(RT_TRACE_BLOCK / 64) * (RT_STACK_MAX - RT_STACK_LDS) * 64 * sizeof(uint2);
+    const int grid_trace = std::max(sc->blocks_closest, sc->blocks_shadow);
+    if ((rc = sc->b_spill.ensure(spill_per_block * grid_trace))) return rc;
+    uint2* spill = (uint2*)sc->b_spill.p;
+
+    const bool want_sync = stats != nullptr || (sc->opt_flags & RT_FLAG_TIMING) || D > 0;
+    Timer tm{sc, st, (sc->opt_flags & RT_FLAG_TIMING) != 0};
+    HIPCHK(hipMemsetAsync(ctl, 0, sizeof(Control), st));
+
+    hipEvent_t ev_total_a = nullptr, ev_total_b = nullptr;
+    if (stats) {
+        HIPCHK(hipEventCreate(&ev_total_a));
+        HIPCHK(hipEventCreate(&ev_total_b));
+        HIPCHK(hipEventRecord(ev_total_a, st));
+    }
+
+    DCamera dc;
+    to_dcamera(cam, dc);
+    const float inv_n = 1.0f / N;   // raytracer.cpp:38
+    const int tiles_per_row = (w + 7) / 8, tile_rows = (h + 7) / 8;
+    const uint32_t total_tiles = (uint32_t)tiles_per_row * tile_rows;
+    const Pool& P = sc->pool;
+    // tiles per chunk: bounded by the chunk option, the record pool and the shadow pool
+    uint64_t max_samples = std::min<uint64_t>(sc->opt_chunk_samples, D > 0 ? P.cap_records / 2 : P.cap_records);
+    if (sc->n_point_lights) max_samples = std::min<uint64_t>(max_samples, P.cap_shadow / sc->n_point_lights);
+    uint32_t tiles_per_chunk = (uint32_t)std::max<uint64_t>(1, max_samples / (64ull * N));
+    if ((uint64_t)tiles_per_chunk * 64 * N > P.cap_records) return fail(RT_ERR_OVERFLOW, "record pool too small for one 8x8 tile at %d spp", N);
+
+    uint32_t chunks = 0;
+    uint64_t peak = 0;
+    uint32_t tile = 0;
+    while (tile < total_tiles) {
+        const uint32_t nt = std::min(tiles_per_chunk, total_tiles - tile);
+        ChunkGeom g{x0, y0, w, h, tiles_per_row, tile, nt * 64u};
+        const uint32_t n_primary = g.n_idx * (uint32_t)N;
+        k_init_chunk<<<1, 64, 0, st>>>(ctl, n_primary);
+        if ((rc = tm.begin(TC_RAYGEN))) return rc;
+        if (N == 1) {
+            k_raygen_single<<<(g.n_idx + 255) / 256, 256, 0, st>>>(dc, g, P);
+        } else {
+            const size_t strideT = g.n_idx;
+            if ((rc = sc->b_mt.ensure(strideT * (624 + (size_t)N) * 4))) return rc;
+            uint32_t* mt = (uint32_t*)sc->b_mt.p;
+            k_raygen_multi<<<(g.n_idx + 255) / 256, 256, 0, st>>>(dc, g, P, mt, mt + strideT * 624, strideT);
+        }
+        if ((rc = tm.end())) return rc;
+        const int grid_flat = 2048;
+        for (int d = 0; d <= D; d++) {
+            if ((rc = tm.begin(TC_CLOSEST))) return rc;
+            k_trace_closest<<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, spill);
+            if ((rc = tm.end())) return rc;
+            if ((rc = tm.begin(TC_SHADE))) return rc;
+            k_shade<<<grid_flat, 256, 0, st>>>(sc->ds, P, ctl, d);
+            k_advance<<<1, 64, 0, st>>>(ctl, P, d);
+            if ((rc = tm.end())) return rc;
+            if (sc->n_point_lights) {
+                if ((rc = tm.begin(TC_SHADOW))) return rc;
+                k_trace_shadow<<<sc->blocks_shadow, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, spill);
+                if ((rc = tm.end())) return rc;
+            }
+        }
+        if ((rc = tm.begin(TC_COMBINE))) return rc;
+        for (int d = D; d >= 0; d--) k_combine<<<grid_flat, 256, 0, st>>>(sc->ds, P, ctl, d);
+        if ((rc = tm.end())) return rc;
+        if ((rc = tm.begin(TC_RESOLVE))) return rc;
+        k_resolve<<<(g.n_idx + 255) / 256, 256, 0, st>>>(dc, g, P, sc->ds.tris, inv_n, d_rgb, stride, d_hits);
+        if ((rc = tm.end())) return rc;
+        HIPCHK(hipGetLastError());
+        chunks++;
+
+        if (D > 0) {
+            // child rays were spawned: the pools may have overflowed
+            HIPCHK(hipMemcpyAsync(sc->h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (sc->h_ctl->overflow & 4u) return fail(RT_ERR_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
+            if (sc->h_ctl->overflow & 3u) {
+                if (tiles_per_chunk == 1) return fail(RT_ERR_OVERFLOW, "ray pool too small for one 8x8 tile; raise RT_OPT_POOL_RECORDS");
+                tiles_per_chunk = std::max(1u, tiles_per_chunk / 2);
+                continue;   // redo this chunk with fewer pixels (counters of the failed try stay: stats are upper bounds then)
+            }
+            peak = std::max<uint64_t>(peak, sc->h_ctl->n_records);
+        } else {
+            peak = std::max<uint64_t>(peak, n_primary);
+        }
+        tile += nt;
+    }
+
+    if (stats) HIPCHK(hipEventRecord(ev_total_b, st));
+    if (want_sync) {
+        HIPCHK(hipMemcpyAsync(sc->h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (sc->h_ctl->overflow & 4u) return fail(RT_ERR_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
+        if (sc->h_ctl->overflow & 3u) return fail(RT_ERR_OVERFLOW, "ray pool overflow");
+    }
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->rays_primary = sc->h_ctl->rays_primary;
+        stats->rays_secondary = sc->h_ctl->rays_secondary;
+        stats->rays_shadow = sc->h_ctl->rays_shadow;
+        stats->records_peak = peak;
+        stats->chunks = chunks;
+        HIPCHK(hipEventElapsedTime(&stats->ms_total, ev_total_a, ev_total_b));
+        (void)hipEventDestroy(ev_total_a);
+        (void)hipEventDestroy(ev_total_b);
+    }
+    // fold kernel timings
+    float acc[TC_COUNT] = {0};
+    uint32_t launches[TC_COUNT] = {0};
+    for (auto& e : sc->ev_used) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { acc[e.cat] += ms; launches[e.cat]++; }
+        sc->ev_free.push_back(e);
+    }
+    sc->ev_used.clear();
+    if (stats) {
+        stats->ms_raygen = acc[TC_RAYGEN]; stats->ms_closest = acc[TC_CLOSEST]; stats->ms_shade = acc[TC_SHADE];
+        stats->ms_shadow = acc[TC_SHADOW]; stats->ms_combine = acc[TC_COMBINE]; stats->ms_resolve = acc[TC_RESOLVE];
+        stats->launches_closest = launches[TC_CLOSEST];
+        stats->launches_shadow = launches[TC_SHADOW];
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+
+int rt_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(RT_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out) {
+    if (!out) return fail(RT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = rt_device_count();
+    if (n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail(RT_ERR_NO_DEVICE, "device %d out of range [0,%d)", device, n);
+    int rc = validate_scene(scene);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device));
+    rt_scene* sc = new rt_scene();
+    sc->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) sc->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess) { delete sc; return fail(RT_ERR_HIP, "hipStreamCreate failed"); }
+    if (hipHostMalloc((void**)&sc->h_ctl, sizeof(Control)) != hipSuccess) { rt_free_scene(sc); return fail(RT_ERR_HIP, "hipHostMalloc failed"); }
+    rc = build_device_scene(sc, scene);
+    if (rc) { rt_free_scene(sc); return rc; }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest, RT_TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    sc->blocks_closest = sc->n_cu * std::min(per_cu, 8);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_shadow, RT_TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    sc->blocks_shadow = sc->n_cu * std::min(per_cu, 8);
+    *out = sc;
+    return RT_OK;
+}
+
+int rt_scene_set_option(rt_scene* s, int option, uint64_t value) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is NULL");
+    switch (option) {
+    case RT_OPT_FLAGS: s->opt_flags = value; return RT_OK;
+    case RT_OPT_POOL_RECORDS:
+        if (value < 4096 || value > (1ull << 31)) return fail(RT_ERR_INVALID, "pool size out of range");
+        s->opt_pool_records = value;
+        return RT_OK;
+    case RT_OPT_CHUNK_SAMPLES:
+        if (value < 64) return fail(RT_ERR_INVALID, "chunk size out of range");
+        s->opt_chunk_samples = value;
+        return RT_OK;
+    default: return fail(RT_ERR_INVALID, "unknown option %d", option);
+    }
+}
+
+int rt_render_tile_device(rt_scene* s, const rt_camera_desc* cam, int x0, int y0, int tile_w, int tile_h, void* d_rgb_out,
+                          size_t rgb_row_stride_bytes, void* d_hit_id_out, rt_stats* stats, void* hip_stream) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is NULL");
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
+    return render_impl(s, cam, x0, y0, tile_w, tile_h, (uint8_t*)d_rgb_out, rgb_row_stride_bytes, (uint32_t*)d_hit_id_out, stats, st);
+}
+
+int rt_render_tile(rt_scene* s, const rt_camera_desc* cam, int x0, int y0, int tile_w, int tile_h, uint8_t* rgb_out,
+                   size_t rgb_row_stride_bytes, uint32_t* hit_id_out, rt_stats* stats) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is NULL");
+    if (!rgb_out || tile_w <= 0 || tile_h <= 0 || rgb_row_stride_bytes < (size_t)tile_w * 3) return fail(RT_ERR_INVALID, "bad output buffer");
+    HIPCHK(hipSetDevice(s->device));
+    const size_t fb_bytes = (size_t)tile_w * tile_h * 3, hit_bytes = (size_t)tile_w * tile_h * 8;
+    int rc = s->b_fb.ensure(fb_bytes);
+    if (rc) return rc;
+    if (hit_id_out && (rc = s->b_hits.ensure(hit_bytes))) return rc;
+    rc = render_impl(s, cam, x0, y0, tile_w, tile_h, (uint8_t*)s->b_fb.p, (size_t)tile_w * 3, hit_id_out ? (uint32_t*)s->b_hits.p : nullptr,
+                     stats, s->stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy2DAsync(rgb_out, rgb_row_stride_bytes, s->b_fb.p, (size_t)tile_w * 3, (size_t)tile_w * 3, tile_h,
+                            hipMemcpyDeviceToHost, s->stream));
+    if (hit_id_out) HIPCHK(hipMemcpyAsync(hit_id_out, s->b_hits.p, hit_bytes, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return RT_OK;
+}
+
+int rt_sync(rt_scene* s) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is NULL");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return RT_OK;
+}
+
+void rt_free_scene(rt_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (DevBuf* b : {&s->b_nodes, &s->b_tris, &s->b_tri_shade, &s->b_vnormals, &s->b_objects, &s->b_top_prims, &s->b_planes,
+                      &s->b_materials, &s->b_lights, &s->b_ray0, &s->b_ray1, &s->b_hit0, &s->b_hit1, &s->b_nrm, &s->b_link,
+                      &s->b_color, &s->b_shadow_rec, &s->b_shadow_lit, &s->b_ctl, &s->b_spill, &s->b_mt, &s->b_fb, &s->b_hits})
+        b->release();
+    for (auto& e : s->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : s->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (s->h_ctl) (void)hipHostFree(s->h_ctl);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+}  // extern "C"

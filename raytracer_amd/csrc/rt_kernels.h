@@ -1,0 +1,729 @@
+// rt_kernels.h — the wavefront pipeline around the traversal:
+//   raygen  -> [ trace_closest -> shade (spawns children + shadow slots) -> trace_shadow ] per depth
+//           -> combine (deepest generation first) -> resolve (sum samples, 8-bit)
+//
+// The reference evaluates ComputeColor/ApplyShading recursively
+// (raytracer.cpp:382-401, 1248-1436).  Here every ray of the recursion tree is
+// a RECORD in a pool; generation g holds the rays of depth g.  Because the
+// point-light path draws no random numbers (PerturbReflection returns early for
+// roughness <= 0, raytracer.cpp:1441), the tree's rays can be traced in any
+// order; the colour of a record is then computed bottom-up with exactly the
+// reference's expression order, so sums round identically.
+#pragma once
+#include "rt_traverse.h"
+
+#define RT_MAX_GEN 32
+#define RT_NO_CHILD 0xFFFFFFFFu
+
+// record flags (DLink.w)
+#define RF_MISS        1u
+#define RF_LIGHTS      2u    // local lighting is evaluated (not an exiting dielectric)
+#define RF_DEAD        4u    // padding lane of an edge tile: no ray
+
+struct Pool {
+    float4*   ray0;        // origin.xyz, time
+    float4*   ray1;        // direction.xyz, live (bits: 1 = live)
+    uint4*    hit0;        // t bits, kind_index, tri, -
+    float2*   hit1;        // beta, gamma
+    float4*   nrm;         // world normal (HitRecord::normal), material id bits
+    uint4*    link;        // child0 (reflect), child1 (refract), shadow_base, flags
+    float4*   color;       // ComputeColor result
+    uint32_t* shadow_rec;  // per shadow slot: owning record
+    uint8_t*  shadow_lit;  // per shadow slot: 1 = !InShadow
+    uint32_t  cap_records, cap_shadow;
+};
+
+struct Control {
+    uint32_t gstart[RT_MAX_GEN + 2];   // generation g = records [gstart[g], gstart[g+1])
+    uint32_t sstart[RT_MAX_GEN + 2];   // shadow slots of generation g
+    uint32_t n_records, n_shadow;      // allocation cursors
+    uint32_t cursor_closest, cursor_shadow;
+    uint32_t overflow;                 // 1: record pool, 2: shadow pool, 4: traversal stack
+    uint32_t pad;
+    unsigned long long rays_primary, rays_secondary, rays_shadow;
+};
+
+// ----------------------------------------------------------------- pixel order
+// A chunk is a run of 8x8 pixel tiles of the render rectangle; idx enumerates
+// tile-major so that the 64 lanes of a wave start as one 8x8 pixel block.
+struct ChunkGeom {
+    int x0, y0, w, h;        // render rectangle inside the image
+    int tiles_per_row;
+    uint32_t tile_begin;     // first tile of this chunk
+    uint32_t n_idx;          // 64 * tiles in this chunk
+};
+__device__ __forceinline__ bool idx_to_pixel(const ChunkGeom& g, uint32_t idx, int& px, int& py) {
+    uint32_t tile = g.tile_begin + (idx >> 6);
+    uint32_t in = idx & 63u;
+    int tx = (int)(tile % (uint32_t)g.tiles_per_row), ty = (int)(tile / (uint32_t)g.tiles_per_row);
+    int lx = tx * 8 + (int)(in & 7u), ly = ty * 8 + (int)(in >> 3);
+    px = g.x0 + lx;
+    py = g.y0 + ly;
+    return lx < g.w && ly < g.h;
+}
+
+// ------------------------------------------------------ libstdc++ RNG restated
+// std::mt19937 / std::shuffle / std::uniform_real_distribution<float> as used at
+// raytracer.cpp:44-69 (libstdc++ 11: bits/random.tcc, bits/stl_algo.h,
+// bits/uniform_int_dist.h).
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+__device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t m) {
+    uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return m ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+// generate_canonical<float,24>: float(u32)/2^32, clamped below 1
+__device__ __forceinline__ float u32_to_unit(uint32_t u) {
+    float r = (float)u * 2.3283064365386963e-10f;   // exact 2^-32 scale == division by 4294967296.0f
+    if (r >= 1.0f) r = 0x1.fffffep-1f;
+    return r;
+}
+// The first five outputs of mt19937(seed) need state words 0..5 and 397..401 of
+// the seeding recurrence only: output k = temper(s[k+397] ^ mix(s[k], s[k+1])).
+__device__ __forceinline__ void mt_first5(uint32_t seed, uint32_t out[5]) {
+#define RT_MT_STEP(prev, i) (1812433253u * ((prev) ^ ((prev) >> 30)) + (uint32_t)(i))
+    const uint32_t s0 = seed;
+    const uint32_t s1 = RT_MT_STEP(s0, 1), s2 = RT_MT_STEP(s1, 2), s3 = RT_MT_STEP(s2, 3), s4 = RT_MT_STEP(s3, 4),
+                   s5 = RT_MT_STEP(s4, 5);
+    uint32_t s = s5;
+#pragma unroll 4
+    for (uint32_t i = 6; i <= 396; i++) s = RT_MT_STEP(s, i);
+    const uint32_t h0 = RT_MT_STEP(s, 397), h1 = RT_MT_STEP(h0, 398), h2 = RT_MT_STEP(h1, 399),
+                   h3 = RT_MT_STEP(h2, 400), h4 = RT_MT_STEP(h3, 401);
+#undef RT_MT_STEP
+    out[0] = mt_temper(mt_mix(s0, s1, h0));
+    out[1] = mt_temper(mt_mix(s1, s2, h1));
+    out[2] = mt_temper(mt_mix(s2, s3, h2));
+    out[3] = mt_temper(mt_mix(s3, s4, h3));
+    out[4] = mt_temper(mt_mix(s4, s5, h4));
+}
+
+// Full generator with its 624-word state in global scratch, one column per
+// thread (word k of thread t at mt[k*stride + t]: coalesced while lanes are in
+// step).  Used when num_samples > 1.
+struct MtGlobal {
+    uint32_t* mt;
+    size_t stride;
+    uint32_t idx;
+    __device__ __forceinline__ uint32_t& w(uint32_t k) { return mt[(size_t)k * stride]; }
+    __device__ void seed(uint32_t s) {
+        w(0) = s;
+        for (uint32_t i = 1; i < 624; i++) {
+            s = 1812433253u * (s ^ (s >> 30)) + i;
+            w(i) = s;
+        }
+        idx = 624;
+    }
+    __device__ void twist() {
+        for (uint32_t k = 0; k < 624; k++) {
+            uint32_t k1 = (k + 1 == 624) ? 0 : k + 1;
+            uint32_t km = (k + 397 >= 624) ? k + 397 - 624 : k + 397;
+            w(k) = mt_mix(w(k), w(k1), w(km));
+        }
+        idx = 0;
+    }
+    __device__ __forceinline__ uint32_t next() {
+        if (idx >= 624) twist();
+        return mt_temper(w(idx++));
+    }
+    __device__ __forceinline__ float uniform() { return u32_to_unit(next()); }
+    // uniform_int_distribution::_S_nd<uint64_t> (Lemire)
+    __device__ uint32_t lemire(uint32_t range) {
+        unsigned long long product = (unsigned long long)next() * range;
+        uint32_t low = (uint32_t)product;
+        if (low < range) {
+            uint32_t threshold = (0u - range) % range;
+            while (low < threshold) {
+                product = (unsigned long long)next() * range;
+                low = (uint32_t)product;
+            }
+        }
+        return (uint32_t)(product >> 32);
+    }
+};
+
+// ComputeRay, raytracer.cpp:343-378
+__device__ __forceinline__ void compute_ray(const DCamera& cam, int j, int i, float jx, float jy, float au, float av,
+                                            V3& o, V3& d) {
+    float su = (j + jx) * cam.pixel_w;
+    float sv = (i + jy) * cam.pixel_h;
+    V3 q = ldv(cam.q), u = ldv(cam.u), v = ldv(cam.v), pos = ldv(cam.pos);
+    V3 sample_point = (q + u * su) - v * sv;
+    if (!cam.dof) {
+        o = pos;
+        d = normalize(sample_point - pos);
+    } else {
+        V3 dir = normalize(pos - sample_point);
+        float t_focal = cam.focus / dot(dir, ldv(cam.w) * -1.0f);
+        V3 focal_point = pos + dir * t_focal;
+        float lens_u = (au - 0.5f) * cam.aperture;
+        float lens_v = (av - 0.5f) * cam.aperture;
+        V3 lens_sample = (pos + u * lens_u) + v * lens_v;
+        o = lens_sample;
+        d = normalize(focal_point - lens_sample);
+    }
+}
+
+__device__ __forceinline__ void write_ray(const Pool& P, uint32_t r, V3 o, V3 d, float time, bool live) {
+    P.ray0[r] = make_float4(o.x, o.y, o.z, time);
+    P.ray1[r] = make_float4(d.x, d.y, d.z, __uint_as_float(live ? 1u : 0u));
+}
+
+__global__ void k_init_chunk(Control* ctl, uint32_t n_primary) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (int g = 0; g < RT_MAX_GEN + 2; g++) { ctl->gstart[g] = n_primary; ctl->sstart[g] = 0; }
+        ctl->gstart[0] = 0;
+        ctl->n_records = n_primary;
+        ctl->n_shadow = 0;
+        ctl->cursor_closest = 0;
+        ctl->cursor_shadow = 0;
+        ctl->overflow = 0;
+    }
+}
+
+// num_samples == 1: one thread per pixel (raytracer.cpp:44-74 with N = 1: the
+// shuffle of one element draws nothing, then five draws).
+__global__ void __launch_bounds__(256) k_raygen_single(DCamera cam, ChunkGeom g, Pool P) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.n_idx) return;
+    int px, py;
+    if (!idx_to_pixel(g, idx, px, py)) {
+        write_ray(P, idx, mk(0, 0, 0), mk(0, 0, 0), 0.f, false);
+        return;
+    }
+    uint32_t u[5];
+    mt_first5((uint32_t)(py * cam.image_w + px), u);
+    // samples_per_side == 1: (0 + xi) / 1
+    float sps = (float)cam.sps;
+    float jx = (0 + u32_to_unit(u[0])) / sps;
+    float jy = (0 + u32_to_unit(u[1])) / sps;
+    float au = (0 + u32_to_unit(u[2])) / sps;
+    float av = (0 + u32_to_unit(u[3])) / sps;
+    float time = u32_to_unit(u[4]);
+    V3 o, d;
+    compute_ray(cam, px, py, jx, jy, au, av, o, d);
+    write_ray(P, idx, o, d, time, true);
+}
+
+// num_samples > 1: one thread per pixel walks its sample sequence; the rays of
+// pixel idx are records idx*N .. idx*N+N-1.
+__global__ void __launch_bounds__(256) k_raygen_multi(DCamera cam, ChunkGeom g, Pool P, uint32_t* mt_scratch,
+                                                      uint32_t* perm_scratch, size_t stride) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.n_idx) return;
+    const int N = cam.num_samples, sps = cam.sps;
+    int px, py;
+    if (!idx_to_pixel(g, idx, px, py)) {
+        for (int s = 0; s < N; s++) write_ray(P, idx * N + s, mk(0, 0, 0), mk(0, 0, 0), 0.f, false);
+        return;
+    }
+    MtGlobal gen;
+    gen.mt = mt_scratch + idx;
+    gen.stride = stride;
+    gen.seed((uint32_t)(py * cam.image_w + px));
+    uint32_t* perm = perm_scratch + idx;
+    for (int k = 0; k < N; k++) perm[(size_t)k * stride] = (uint32_t)k;
+    // std::shuffle, bits/stl_algo.h (pair path; N*N <= 2^32-1 is checked on the host)
+    {
+        int i = 1;
+        if ((N % 2) == 0) {
+            uint32_t dpos = gen.lemire(2);
+            uint32_t a = perm[(size_t)i * stride], b = perm[(size_t)dpos * stride];
+            perm[(size_t)i * stride] = b; perm[(size_t)dpos * stride] = a;
+            i++;
+        }
+        while (i < N) {
+            uint32_t swap_range = (uint32_t)i + 1, b1 = swap_range + 1;
+            uint32_t x = gen.lemire(swap_range * b1);
+            uint32_t p0 = x / b1, p1 = x % b1;
+            uint32_t a = perm[(size_t)i * stride], b = perm[(size_t)p0 * stride];
+            perm[(size_t)i * stride] = b; perm[(size_t)p0 * stride] = a;
+            i++;
+            a = perm[(size_t)i * stride]; b = perm[(size_t)p1 * stride];
+            perm[(size_t)i * stride] = b; perm[(size_t)p1 * stride] = a;
+            i++;
+        }
+    }
+    const float fs = (float)sps;
+    for (int s = 0; s < N; s++) {
+        int sx = s % sps, sy = s / sps;
+        float jx = (sx + gen.uniform()) / fs;
+        float jy = (sy + gen.uniform()) / fs;
+        int ai = (int)perm[(size_t)s * stride];
+        int ax = ai % sps, ay = ai / sps;
+        float au = (ax + gen.uniform()) / fs;
+        float av = (ay + gen.uniform()) / fs;
+        float time = gen.uniform();
+        V3 o, d;
+        compute_ray(cam, px, py, jx, jy, au, av, o, d);
+        write_ray(P, idx * N + s, o, d, time, true);
+    }
+}
+
+// ------------------------------------------------------------- trace kernels
+struct WaveWork {
+    uint32_t lane, wave;
+    __device__ __forceinline__ WaveWork() : lane(threadIdx.x & 63u), wave(threadIdx.x >> 6) {}
+    // Persistent-thread work fetch: one atomic per wave per 64 items.
+    __device__ __forceinline__ uint32_t grab(uint32_t* cursor) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(cursor, 64u);
+        return __builtin_amdgcn_readfirstlane(base);
+    }
+};
+
+__device__ __forceinline__ TraceStack make_stack(uint32_t* s_link, float* s_t, uint2* spill, const WaveWork& ww) {
+    TraceStack st;
+    st.lds_link = s_link + ww.wave * (RT_STACK_LDS * 64);
+    st.lds_t = s_t + ww.wave * (RT_STACK_LDS * 64);
+    size_t wave_slot = (size_t)blockIdx.x * (RT_TRACE_BLOCK / 64) + ww.wave;
+    st.spill = spill + wave_slot * (size_t)((RT_STACK_MAX - RT_STACK_LDS) * 64);
+    st.lane = ww.lane;
+    st.sp = 0;
+    st.overflow = 0;
+    return st;
+}
+
+// FindClosestHit's search part (raytracer.cpp:405-444) for generation `gen`.
+__global__ void __launch_bounds__(RT_TRACE_BLOCK) k_trace_closest(DScene S, Pool P, Control* ctl, int gen, uint2* spill) {
+    __shared__ uint32_t s_link[(RT_TRACE_BLOCK / 64) * RT_STACK_LDS * 64];
+    __shared__ float s_t[(RT_TRACE_BLOCK / 64) * RT_STACK_LDS * 64];
+    WaveWork ww;
+    TraceStack st = make_stack(s_link, s_t, spill, ww);
+    const uint32_t begin = ctl->gstart[gen], end = ctl->gstart[gen + 1];
+    unsigned long long traced = 0;   // wave-uniform
+    for (;;) {
+        // every lane of the wave reaches this point together: the body below is
+        // one structured `if`, and the exit test is wave-uniform
+        uint32_t base = begin + ww.grab(&ctl->cursor_closest);
+        if (base >= end) break;
+        const uint32_t r = base + ww.lane;
+        const bool in_range = r < end;
+        float4 r0 = make_float4(0, 0, 0, 0), r1 = make_float4(0, 0, 0, 0);
+        if (in_range) { r0 = P.ray0[r]; r1 = P.ray1[r]; }
+        HitOut h;
+        h.t = RT_FLT_MAX;
+        h.kind_index = 0xFFFFFFFFu;
+        h.tri = 0;
+        h.beta = 0.f;
+        h.gamma = 0.f;
+        const bool live = in_range && __float_as_uint(r1.w) != 0u;
+        traced += __popcll(__ballot(live));
+        if (live) {
+            V3 o = mk(r0.x, r0.y, r0.z), d = mk(r1.x, r1.y, r1.z);
+            float minT = RT_FLT_MAX;
+            bool has = false;
+            for (uint32_t i = 0; i < S.n_planes; i++) {   // raytracer.cpp:423-435
+                float t;
+                if (plane_test(o, d, S.planes[i], minT, t)) {
+                    minT = t;
+                    has = true;
+                    h.kind_index = (RT_KIND_PLANE << 28) | i;
+                }
+            }
+            has = traverse<false>(S, o, d, r0.w, minT, has, h, st);
+            if (!has) h.kind_index = 0xFFFFFFFFu;
+        }
+        if (in_range) {
+            P.hit0[r] = make_uint4(__float_as_uint(h.t), h.kind_index, h.tri, 0u);
+            P.hit1[r] = make_float2(h.beta, h.gamma);
+        }
+    }
+    if (st.overflow) atomicOr(&ctl->overflow, 4u);
+    if (traced && ww.lane == 0) atomicAdd(gen == 0 ? &ctl->rays_primary : &ctl->rays_secondary, traced);
+}
+
+// InShadow, raytracer.cpp:1008-1244, one shadow slot per (record, point light).
+__global__ void __launch_bounds__(RT_TRACE_BLOCK) k_trace_shadow(DScene S, Pool P, Control* ctl, int gen, uint2* spill) {
+    __shared__ uint32_t s_link[(RT_TRACE_BLOCK / 64) * RT_STACK_LDS * 64];
+    __shared__ float s_t[(RT_TRACE_BLOCK / 64) * RT_STACK_LDS * 64];
+    WaveWork ww;
+    TraceStack st = make_stack(s_link, s_t, spill, ww);
+    const uint32_t begin = ctl->sstart[gen], end = ctl->sstart[gen + 1];
+    unsigned long long traced = 0;
+    for (;;) {
+        uint32_t base = begin + ww.grab(&ctl->cursor_shadow);
+        if (base >= end) break;
+        const uint32_t i = base + ww.lane;
+        const bool in_range = i < end;
+        traced += __popcll(__ballot(in_range));
+        if (in_range) {
+        const uint32_t r = P.shadow_rec[i];
+        const uint32_t light = i - P.link[r].z;
+        const float4 r0 = P.ray0[r], r1 = P.ray1[r], nn = P.nrm[r];
+        const float tHit = __uint_as_float(P.hit0[r].x);
+        V3 o = mk(r0.x, r0.y, r0.z), d = mk(r1.x, r1.y, r1.z);
+        V3 x = o + d * tHit;                                   // raytracer.cpp:447
+        V3 n = mk(nn.x, nn.y, nn.z);
+        V3 n_shading = (dot(n, d) < 0.0f) ? n : n * -1.0f;     // raytracer.cpp:1258-1265
+        const DPointLight L = S.point_lights[light];
+        V3 toLight = mk(L.px, L.py, L.pz) - x;
+        float dist = vlen(toLight);
+        V3 so = x + n_shading * S.shadow_eps;
+        V3 sd = vdiv(toLight, dist);
+        float minT = dist;
+        bool shadow = false;
+        for (uint32_t k = 0; k < S.n_planes && !shadow; k++) {
+            float t;
+            if (plane_test(so, sd, S.planes[k], minT, t)) shadow = true;
+        }
+        if (!shadow) {
+            HitOut h;
+            shadow = traverse<true>(S, so, sd, r0.w, minT, false, h, st);
+        }
+        P.shadow_lit[i] = shadow ? 0 : 1;
+        }
+    }
+    if (st.overflow) atomicOr(&ctl->overflow, 4u);
+    if (traced && ww.lane == 0) atomicAdd(&ctl->rays_shadow, traced);
+}
+
+// ------------------------------------------------------------------- shading
+// Everything ApplyShading derives from (ray, hit point, normal, material) before
+// it needs child colours or shadow results (raytracer.cpp:1250-1345).
+struct ShadeCtx {
+    V3 x, n_shading, w0;
+    uint32_t type;
+    // mirror / conductor
+    V3 wr;                 // reflection direction
+    V3 refl_origin;
+    float Fr;              // conductor / dielectric Fresnel
+    // dielectric
+    bool entering, tir;
+    V3 wt, refr_origin;
+};
+
+// Fresnel_Dielectric, raytracer.cpp:1459-1470
+__device__ __forceinline__ float fresnel_dielectric(float cosTheta, float cosPhi, float n1, float n2) {
+    float r_par = (n2 * cosTheta - n1 * cosPhi) / (n2 * cosTheta + n1 * cosPhi);
+    float r_perp = (n1 * cosTheta - n2 * cosPhi) / (n1 * cosTheta + n2 * cosPhi);
+    return (r_par * r_par + r_perp * r_perp) * 0.5f;
+}
+// Fresnel_Conductor, raytracer.cpp:1472-1488
+__device__ __forceinline__ float fresnel_conductor(float cosTheta, float n, float k) {
+    float cos_sq = cosTheta * cosTheta;
+    float n_sq = n * n;
+    float k_sq = k * k;
+    float two_n_cos = 2.0f * n * cosTheta;
+    float rs_num = (n_sq + k_sq) - two_n_cos + cos_sq;
+    float rs_den = (n_sq + k_sq) + two_n_cos + cos_sq;
+    float R_S = rs_num / rs_den;
+    float rp_num = (n_sq + k_sq) * cos_sq - two_n_cos + 1;
+    float rp_den = (n_sq + k_sq) * cos_sq + two_n_cos + 1;
+    float R_P = rp_num / rp_den;
+    return (R_S + R_P) * 0.5f;
+}
+
+__device__ __forceinline__ void shade_ctx(const DScene& S, const DMaterial& mat, V3 o, V3 d, float tHit, V3 n_original,
+                                          ShadeCtx& c) {
+    c.x = o + d * tHit;
+    c.n_shading = (dot(n_original, d) < 0.0f) ? n_original : n_original * -1.0f;
+    c.w0 = normalize(o - c.x);
+    c.type = mat.type;
+    c.entering = true;
+    c.tir = false;
+    c.Fr = 0.f;
+    const float eps = S.shadow_eps;
+    if (mat.type == RT_MAT_MIRROR || mat.type == RT_MAT_CONDUCTOR) {
+        c.wr = normalize((c.n_shading * 2.0f) * dot(c.n_shading, c.w0) - c.w0);   // :1274 / :1286
+        c.refl_origin = c.x + c.n_shading * eps;
+        if (mat.type == RT_MAT_CONDUCTOR) c.Fr = fresnel_conductor(dot(c.w0, c.n_shading), mat.ior, mat.absorb_index);
+    } else if (mat.type == RT_MAT_DIELECTRIC) {                                    // :1301-1362
+        c.entering = dot(n_original, d) < 0.0f;
+        V3 normal = c.entering ? n_original : n_original * -1.0f;
+        float etaI = c.entering ? 1.0f : mat.ior;
+        float etaT = c.entering ? mat.ior : 1.0f;
+        float eta = etaI / etaT;
+        float cosI = dot(c.w0, normal);
+        float one_minus = 1.0f - cosI * cosI;
+        float sin2I = (0.0f < one_minus) ? one_minus : 0.0f;
+        float sin2T = eta * eta * sin2I;
+        c.wr = normalize((normal * 2.0f) * cosI - c.w0);
+        c.refl_origin = c.x + normal * eps;
+        if (sin2T >= 1.0f) {
+            c.tir = true;
+        } else {
+            float cosT = __fsqrt_rn(1.0f - sin2T);
+            c.Fr = fresnel_dielectric(cosI, cosT, etaI, etaT);
+            c.wt = normalize((c.w0 * -1.0f) * eta + normal * (eta * cosI - cosT));
+            c.refr_origin = c.x - normal * eps;
+        }
+    }
+}
+
+// Normal reconstruction of FindClosestHit, raytracer.cpp:447-517.
+__device__ __forceinline__ V3 hit_normal(const DScene& S, uint32_t kind_index, uint32_t tri, float beta, float gamma,
+                                         V3 hit_x, int& material_id) {
+    const uint32_t kind = kind_index >> 28, index = kind_index & 0x0FFFFFFFu;
+    V3 normal = mk(0, 0, 0);
+    if (kind == RT_KIND_MESH) {
+        const DObject& ob = S.objects[S.mesh_obj_base + index];
+        material_id = ob.material_id;
+        const DTriShade ts = S.tri_shade[tri];
+        V3 objN;
+        if (ob.flags & RT_OBJ_SMOOTH) {
+            float4 a4 = S.vnormals[ts.i0 - 1], b4 = S.vnormals[ts.i1 - 1], c4 = S.vnormals[ts.i2 - 1];
+            float alpha = 1.f - beta - gamma;
+            objN = normalize((mk(a4.x, a4.y, a4.z) * alpha + mk(b4.x, b4.y, b4.z) * beta) + mk(c4.x, c4.y, c4.z) * gamma);
+        } else {
+            objN = mk(ts.nx, ts.ny, ts.nz);
+        }
+        const bool xf = (ob.flags & RT_OBJ_HAS_TRANSFORM) != 0;
+        if (xf && (ob.flags & DOBJ_NEG_DET)) objN = objN * -1.0f;
+        normal = xf ? normalize(xf_vector_transposed(ob.Minv, objN)) : objN;
+    } else if (kind == RT_KIND_TRIANGLE) {
+        const DObject& ob = S.objects[S.tri_obj_base + index];
+        material_id = ob.material_id;
+        V3 objN = mk(ob.p[9], ob.p[10], ob.p[11]);
+        const bool xf = (ob.flags & RT_OBJ_HAS_TRANSFORM) != 0;
+        normal = xf ? normalize(xf_vector_transposed(ob.Minv, objN)) : objN;
+        if (xf && (ob.flags & DOBJ_NEG_DET)) normal = normal * -1.0f;
+    } else if (kind == RT_KIND_SPHERE) {
+        const DObject& ob = S.objects[S.sphere_obj_base + index];
+        material_id = ob.material_id;
+        V3 c = mk(ob.p[0], ob.p[1], ob.p[2]);
+        const bool xf = (ob.flags & RT_OBJ_HAS_TRANSFORM) != 0;
+        if (xf) {
+            V3 objHit = xf_point(ob.Minv, hit_x);
+            V3 objN = normalize(objHit - c);
+            normal = normalize(xf_vector_transposed(ob.Minv, objN));
+        } else {
+            normal = normalize(hit_x - c);
+        }
+        if (xf && (ob.flags & DOBJ_NEG_DET)) normal = normal * -1.0f;
+    } else {   // plane
+        const DPlane& p = S.planes[index];
+        material_id = p.material_id;
+        normal = mk(p.nx, p.ny, p.nz);
+    }
+    return normal;
+}
+
+// Wave-aggregated allocation: every lane asks for `n` (0..2) consecutive slots.
+__device__ __forceinline__ uint32_t wave_alloc(uint32_t* counter, uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const unsigned long long m1 = __ballot(n >= 1), m2 = __ballot(n >= 2);
+    const uint32_t total = __popcll(m1) + __popcll(m2);
+    uint32_t base = 0;
+    if (total) {
+        if (lane == 0) base = atomicAdd(counter, total);
+        base = __builtin_amdgcn_readfirstlane(base);
+    }
+    return base + __popcll(m1 & lt) + __popcll(m2 & lt);
+}
+// same for an arbitrary per-lane count (shadow slots: n_point_lights per lit record)
+__device__ __forceinline__ uint32_t wave_alloc_n(uint32_t* counter, uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t v = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl += v;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    uint32_t base = 0;
+    if (total) {
+        if (lane == 0) base = atomicAdd(counter, total);
+        base = __builtin_amdgcn_readfirstlane(base);
+    }
+    return base + incl - n;
+}
+
+// After the closest-hit search of generation `gen`: finish FindClosestHit
+// (normal, material), decide which child rays ApplyShading will ask for
+// (raytracer.cpp:1272-1352) and which shadow tests (raytracer.cpp:1371-1377),
+// and append them to the pools.  This is the ray-compaction step: only live
+// continuations get a slot (ballot/popcount prefix, one atomic per wave).
+__global__ void __launch_bounds__(256) k_shade(DScene S, Pool P, Control* ctl, int gen) {
+    const uint32_t begin = ctl->gstart[gen], end = ctl->gstart[gen + 1];
+    const uint32_t span = end - begin;
+    const uint32_t rounds = (span + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+    for (uint32_t it = 0; it < rounds; it++) {
+        const uint32_t off = (it * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        const bool valid = off < span;
+        const uint32_t r = begin + (valid ? off : 0);
+        uint32_t n_child = 0, n_shadow = 0, flags = RF_MISS;
+        ShadeCtx c;
+        float time = 0.f;
+        c.type = RT_MAT_NONE;
+        c.tir = false;
+        if (valid) {
+            const float4 r0 = P.ray0[r], r1 = P.ray1[r];
+            const uint4 h0 = P.hit0[r];
+            time = r0.w;
+            if (__float_as_uint(r1.w) == 0u) {
+                flags = RF_MISS | RF_DEAD;
+            } else if (h0.y != 0xFFFFFFFFu) {
+                const float2 h1 = P.hit1[r];
+                V3 o = mk(r0.x, r0.y, r0.z), d = mk(r1.x, r1.y, r1.z);
+                const float tHit = __uint_as_float(h0.x);
+                V3 hit_x = o + d * tHit;
+                int material_id = 1;
+                V3 n = hit_normal(S, h0.y, h0.z, h1.x, h1.y, hit_x, material_id);
+                P.nrm[r] = make_float4(n.x, n.y, n.z, __int_as_float(material_id));
+                const DMaterial& mat = S.materials[material_id - 1];
+                shade_ctx(S, mat, o, d, tHit, n, c);
+                flags = 0;
+                const bool can_recurse = gen < S.max_depth;   // child depth = gen+1 <= max (raytracer.cpp:384)
+                if (c.type == RT_MAT_MIRROR || c.type == RT_MAT_CONDUCTOR) n_child = can_recurse ? 1 : 0;
+                else if (c.type == RT_MAT_DIELECTRIC) n_child = can_recurse ? (c.tir ? 1 : 2) : 0;
+                if (!(c.type == RT_MAT_DIELECTRIC && !c.entering)) {   // raytracer.cpp:1364-1366
+                    flags |= RF_LIGHTS;
+                    n_shadow = S.n_point_lights;
+                }
+            }
+        }
+        uint32_t child = wave_alloc(&ctl->n_records, n_child);
+        uint32_t sbase = wave_alloc_n(&ctl->n_shadow, n_shadow);
+        if (!valid) continue;
+        uint32_t c0 = RT_NO_CHILD, c1 = RT_NO_CHILD;
+        if (n_child) {
+            if (child + n_child <= P.cap_records) {
+                c0 = child;
+                write_ray(P, c0, c.refl_origin, c.wr, time, true);
+                if (n_child == 2) {
+                    c1 = child + 1;
+                    write_ray(P, c1, c.refr_origin, c.wt, time, true);
+                }
+            } else {
+                atomicOr(&ctl->overflow, 1u);
+            }
+        }
+        if (n_shadow) {
+            if (sbase + n_shadow <= P.cap_shadow) {
+                for (uint32_t l = 0; l < n_shadow; l++) P.shadow_rec[sbase + l] = r;
+            } else {
+                atomicOr(&ctl->overflow, 2u);
+                flags &= ~RF_LIGHTS;
+            }
+        }
+        P.link[r] = make_uint4(c0, c1, sbase, flags);
+    }
+}
+
+// Close generation gen: fix the boundaries of the next generation and of this
+// generation's shadow slots, and rewind the work cursors.
+__global__ void k_advance(Control* ctl, Pool P, int gen) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t nr = ctl->n_records < P.cap_records ? ctl->n_records : P.cap_records;
+        uint32_t ns = ctl->n_shadow < P.cap_shadow ? ctl->n_shadow : P.cap_shadow;
+        ctl->n_records = nr;
+        ctl->n_shadow = ns;
+        for (int g = gen + 2; g < RT_MAX_GEN + 2; g++) ctl->gstart[g] = nr;
+        for (int g = gen + 1; g < RT_MAX_GEN + 2; g++) ctl->sstart[g] = ns;
+        ctl->cursor_closest = 0;
+        ctl->cursor_shadow = 0;
+    }
+}
+
+// ComputeDiffuseAndSpecular, raytracer.cpp:1490-1520
+__device__ __forceinline__ V3 diffuse_specular(const DMaterial& mat, const DPointLight& L, V3 point, V3 normal, V3 w0) {
+    V3 Lv = mk(L.px, L.py, L.pz) - point;
+    V3 wi = normalize(Lv);
+    float cos_theta = dot(wi, normal);
+    if (cos_theta < 0.0f) return mk(0.0f, 0.0f, 0.f);
+    float d_sq = dot(Lv, Lv);
+    V3 irradiance = vdiv(mk(L.ix, L.iy, L.iz), d_sq);
+    V3 diffuse = emul(ldv(mat.kd) * cos_theta, irradiance);
+    V3 h = normalize(wi + w0);
+    float cos_alpha = dot(normal, h);
+    if (cos_alpha < 0.0f) return diffuse;
+    V3 spec = emul(ldv(mat.ks) * rt_powf(cos_alpha, mat.phong), irradiance);
+    return diffuse + spec;
+}
+
+// ApplyShading's colour expression (raytracer.cpp:1251-1377) for the records of
+// generation gen, children already combined.
+__global__ void __launch_bounds__(256) k_combine(DScene S, Pool P, Control* ctl, int gen) {
+    const uint32_t begin = ctl->gstart[gen], end = ctl->gstart[gen + 1];
+    for (uint32_t r = begin + blockIdx.x * blockDim.x + threadIdx.x; r < end; r += gridDim.x * blockDim.x) {
+        const uint4 lk = P.link[r];
+        V3 color = mk(0, 0, 0);
+        if (lk.w & RF_MISS) {
+            if (gen == 0 && !(lk.w & RF_DEAD)) color = ldv(S.background);   // raytracer.cpp:393-400
+            P.color[r] = make_float4(color.x, color.y, color.z, 0.f);
+            continue;
+        }
+        const float4 r0 = P.ray0[r], r1 = P.ray1[r], nn = P.nrm[r];
+        const float tHit = __uint_as_float(P.hit0[r].x);
+        V3 o = mk(r0.x, r0.y, r0.z), d = mk(r1.x, r1.y, r1.z), n = mk(nn.x, nn.y, nn.z);
+        const DMaterial& mat = S.materials[__float_as_int(nn.w) - 1];
+        ShadeCtx c;
+        shade_ctx(S, mat, o, d, tHit, n, c);
+        V3 child0 = mk(0, 0, 0), child1 = mk(0, 0, 0);   // ComputeColor beyond max depth: (0,0,0) (raytracer.cpp:384-386)
+        if (lk.x != RT_NO_CHILD) { float4 v = P.color[lk.x]; child0 = mk(v.x, v.y, v.z); }
+        if (lk.y != RT_NO_CHILD) { float4 v = P.color[lk.y]; child1 = mk(v.x, v.y, v.z); }
+        V3 km = ldv(mat.km);
+        if (c.type == RT_MAT_MIRROR) {
+            color = color + emul(km, child0);
+        } else if (c.type == RT_MAT_CONDUCTOR) {
+            V3 reflectColor = emul(km, child0);
+            color = color + reflectColor * c.Fr;
+        } else if (c.type == RT_MAT_DIELECTRIC) {
+            if (c.tir) {
+                color = color + emul(km, child0);
+            } else {
+                V3 reflectColor = emul(km, child0);
+                V3 refractColor = child1;
+                if (!c.entering) {
+                    float dd = vlen(c.x - o);
+                    refractColor.x *= rt_expf(-mat.absorb_coef[0] * dd);
+                    refractColor.y *= rt_expf(-mat.absorb_coef[1] * dd);
+                    refractColor.z *= rt_expf(-mat.absorb_coef[2] * dd);
+                }
+                color = (color + reflectColor * c.Fr) + refractColor * (1.0f - c.Fr);
+            }
+        }
+        if (lk.w & RF_LIGHTS) {
+            color = color + emul(ldv(S.ambient), ldv(mat.ka));
+            for (uint32_t l = 0; l < S.n_point_lights; l++) {
+                if (P.shadow_lit[lk.z + l]) color = color + diffuse_specular(mat, S.point_lights[l], c.x, c.n_shading, c.w0);
+            }
+        }
+        P.color[r] = make_float4(color.x, color.y, color.z, 0.f);
+    }
+}
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) {   // MathF.h:11-16
+    if (v < lo) return lo;
+    if (v > hi) return hi;
+    return v;
+}
+
+// raytracer.cpp:77-85: sum the samples in order, scale, clamp, truncate.
+__global__ void __launch_bounds__(256) k_resolve(DCamera cam, ChunkGeom g, Pool P, const DTri* tris, float inv_n,
+                                                 uint8_t* rgb, size_t row_stride, uint32_t* hit_ids) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.n_idx) return;
+    int px, py;
+    if (!idx_to_pixel(g, idx, px, py)) return;
+    const int N = cam.num_samples;
+    V3 sum = mk(0.0f, 0.0f, 0.0f);
+    for (int s = 0; s < N; s++) {
+        float4 c = P.color[(size_t)idx * N + s];
+        sum = sum + mk(c.x, c.y, c.z);
+    }
+    V3 c = sum * inv_n;
+    const int lx = px - g.x0, ly = py - g.y0;
+    uint8_t* o = rgb + (size_t)ly * row_stride + (size_t)lx * 3;
+    o[0] = (uint8_t)clampf(c.x, 0.0f, 255.0f);
+    o[1] = (uint8_t)clampf(c.y, 0.0f, 255.0f);
+    o[2] = (uint8_t)clampf(c.z, 0.0f, 255.0f);
+    if (hit_ids) {
+        const uint4 h0 = P.hit0[(size_t)idx * N];
+        uint32_t w0 = 0xFFFFFFFFu, w1 = 0xFFFFFFFFu;
+        if (h0.y != 0xFFFFFFFFu) {
+            w0 = h0.y;
+            w1 = ((h0.y >> 28) == RT_KIND_MESH) ? tris[h0.z].face : 0u;
+        }
+        uint32_t* ho = hit_ids + ((size_t)ly * g.w + lx) * 2;
+        ho[0] = w0;
+        ho[1] = w1;
+    }
+}

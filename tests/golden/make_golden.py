@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures from the reference itself.
+
+Run in the build container (needs /root/reference and oracle/_ref/libref_oracle.so,
+built by `make -C oracle ref`):
+
+    python tests/golden/make_golden.py
+
+For every scene listed below it writes, under tests/golden/:
+  <name>.rtscene.gz  the scene as the REFERENCE's parser + BVH builders produce it,
+                     flattened by raytracer_amd/host/rt_flatten.hpp (values only)
+  <name>.png         the image rendered by the reference's own functions
+                     (ComputeRay/ComputeColor under the loop of raytracer.cpp:40-87);
+                     where the reference repository holds its author's render of
+                     the same scene with HEAD, the script asserts both are identical
+  <name>.hits.npz    primary-hit identity per pixel straight from the reference's
+                     IntersectTopBVH / IntersectsPlane: kind, index, face i0,i1,i2, t bits
+Fixtures are data (inputs + expected outputs); no reference source is stored.
+"""
+import gzip
+import os
+import shutil
+import sys
+
+import numpy as np
+from PIL import Image
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+from oracle import binding as ob  # noqa: E402
+
+REF = "/root/reference/blog/"
+# name, scene json, author's committed render of HEAD (or None), crop (x0,y0,w,h) or None
+SCENES = [
+    ("hw1_simple", "hw1/inputs/simple.json", None, None),
+    ("hw1_spheres_mirror", "hw1/inputs/spheres_mirror.json", None, None),
+    ("hw1_cornellbox_recursive", "hw1/inputs/cornellbox_recursive.json", None, None),
+    ("hw1_two_spheres", "hw1/inputs/two_spheres.json", None, None),
+    ("hw1_spheres_with_plane", "hw1/inputs/spheres_with_plane.json", None, None),
+    ("hw2_mirror_room", "hw2/inputs/mirror_room.json", "hw3/my_outputs/from_hw2/mirror_room.png", None),
+    ("hw2_metal_glass_plates", "hw2/inputs/metal_glass_plates.json", "hw3/my_outputs/from_hw2/metal_glass_plates.png", None),
+    ("hw2_two_berserkers", "hw2/inputs/akif_uslu/berserker/two_berserkers.json", "hw3/my_outputs/from_hw2/two_berserkers.png", None),
+    ("hw2_ellipsoids", "hw2/inputs/ellipsoids.json", None, None),
+    ("hw2_simple_transform", "hw2/inputs/simple_transform.json", None, None),
+    ("hw3_spheres_dof", "hw3/inputs/spheres_dof.json", "hw3/my_outputs/spheres_dof.png", None),
+    ("hw3_cornellbox_boxes_dynamic", "hw3/inputs/cornellbox_boxes_dynamic.json", "hw3/my_outputs/cornellbox_boxes_dynamic.png", None),
+    # RNG-coupled shading (area light / glossy): oracle-only goldens for now
+    ("hw3_cornellbox_area", "hw3/inputs/cornellbox_area.json", "hw3/my_outputs/cornellbox_area.png", None),
+    ("hw3_metal_glass_plates", "hw3/inputs/metal_glass_plates.json", "hw3/my_outputs/metal_glass_plates.png", None),
+    ("hw3_cornellbox_brushed_metal", "hw3/inputs/cornellbox_brushed_metal.json", "hw3/my_outputs/cornellbox_brushed_metal.png", None),
+]
+
+
+def main():
+    only = set(sys.argv[1:])
+    for name, js, author_png, crop in SCENES:
+        if only and name not in only:
+            continue
+        ob.ref_load(REF + js)
+        blob = os.path.join(HERE, name + ".rtscene")
+        assert ob.ref().ref_save_flat(blob.encode()) == 0
+        with open(blob, "rb") as f, gzip.GzipFile(blob + ".gz", "wb", mtime=0) as g:
+            shutil.copyfileobj(f, g)
+        os.remove(blob)
+        from raytracer_amd.ffi import CameraDesc
+        import ctypes as C
+        cam = CameraDesc()
+        ob.ref().ref_camera(0, C.byref(cam))
+        w, h = cam.image_width, cam.image_height
+        rgb, sec = ob.ref_render(0, 0, 0, w, h)
+        if author_png:
+            g = np.array(Image.open(REF + author_png).convert("RGB"))
+            assert g.shape == rgb.shape and (g == rgb).all(), f"{name}: reference build differs from the author's render"
+        Image.fromarray(rgb).save(os.path.join(HERE, name + ".png"), optimize=True)
+        hits = ob.ref_primary_hits(0, 0, 0, w, h)
+        np.savez_compressed(os.path.join(HERE, name + ".hits.npz"), hits=hits)
+        print(f"{name}: {w}x{h} spp={cam.num_samples} ref {sec:.1f}s  author-render-identical={bool(author_png)}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
