@@ -28,6 +28,8 @@ const char*           rth_scene_camera_name(const rth_scene* s, int i);
 /* replace camera i's resolution / sample count, recomputing pixel size and the
  * stratification side exactly as parser.cpp:405-443 does (q is unchanged). */
 int                   rth_scene_set_camera_resolution(rth_scene* s, int i, int width, int height, int num_samples);
+/* override Scene::max_recursion_depth (tests sweep it) */
+int                   rth_scene_set_max_depth(rth_scene* s, int max_recursion_depth);
 void                  rth_scene_free(rth_scene* s);
 const char*           rth_last_error(void);
 

@@ -877,6 +877,43 @@ int rto_render(const rt_scene_desc* sc, const rt_camera_desc* cam, int x0, int y
     return RT_OK;
 }
 
+/* Intermediates of one pixel's FIRST sample, for debugging a parity failure:
+ * out[0..2] ray origin, [3..5] direction, [6] time, [7] hit?, [8] minT, [9] kind, [10] index,
+ * [11..13] normal, [14..16] hit point, [17..19] n_shading, [20+l] !InShadow(light l) for l < 8. */
+int rto_probe(const rt_scene_desc* sc, const rt_camera_desc* cam, int px, int py, float* out) {
+    thread_ctr tc;
+    memset(&tc, 0, sizeof(tc));
+    ctx_t cx = {sc, cam, &tc};
+    mt19937* g = (mt19937*)malloc(sizeof(mt19937));
+    const int N = cam->num_samples, sps = cam->samples_per_side;
+    int* perm = (int*)malloc(sizeof(int) * (size_t)N);
+    mt_seed(g, (uint32_t)(py * cam->image_width + px));
+    for (int k = 0; k < N; k++) perm[k] = k;
+    shuffle_ints(perm, N, g);
+    float jx = (0 + mt_uniform(g)) / sps, jy = (0 + mt_uniform(g)) / sps;
+    int ai = perm[0];
+    float au = (ai % sps + mt_uniform(g)) / sps, av = (ai / sps + mt_uniform(g)) / sps;
+    float time = mt_uniform(g);
+    ray_t ray = compute_ray(cam, px, py, jx, jy, au, av, time);
+    memset(out, 0, 28 * sizeof(float));
+    out[0] = ray.o.x; out[1] = ray.o.y; out[2] = ray.o.z; out[3] = ray.d.x; out[4] = ray.d.y; out[5] = ray.d.z; out[6] = time;
+    hit_record hr;
+    hit_info hi;
+    if (find_closest_hit(&cx, &ray, &hr, &hi)) {
+        out[7] = 1;
+        out[9] = (float)hi.kind; out[10] = (float)hi.index;
+        out[11] = hr.n.x; out[12] = hr.n.y; out[13] = hr.n.z;
+        out[14] = hr.x.x; out[15] = hr.x.y; out[16] = hr.x.z;
+        v3 ns = (dot(hr.n, ray.d) < 0.0f) ? hr.n : mul(hr.n, -1);
+        out[17] = ns.x; out[18] = ns.y; out[19] = ns.z;
+        for (uint32_t l = 0; l < sc->n_point_lights && l < 8; l++)
+            out[20 + l] = in_shadow(&cx, hr.x, &sc->point_lights[l], ns, sc->shadow_ray_epsilon, time) ? 0.f : 1.f;
+    }
+    free(g);
+    free(perm);
+    return RT_OK;
+}
+
 /* RNG known-answer helper for tests: the first `n_u32` raw outputs of
  * mt19937(seed), then shuffle of [0,n_perm) with a fresh mt19937(seed), then
  * n_f uniform floats drawn right after that shuffle. */

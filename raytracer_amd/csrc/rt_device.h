@@ -121,7 +121,7 @@ __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y 
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {                                                   // Vec3f.h:20-24
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-__device__ __forceinline__ float vlen(V3 a) { return __fsqrt_rn(a.x * a.x + a.y * a.y + a.z * a.z); }   // Vec3f.h:26-28
+__device__ __forceinline__ float vlen(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }   // Vec3f.h:26-28
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }

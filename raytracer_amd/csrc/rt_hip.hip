@@ -638,6 +638,18 @@ int rt_render_tile(rt_scene* s, const rt_camera_desc* cam, int x0, int y0, int t
     return RT_OK;
 }
 
+int rt_debug_fetch(rt_scene* s, int which, uint64_t first, uint64_t count, void* out) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "NULL argument");
+    const DevBuf* b[7] = {&s->b_ray0, &s->b_ray1, &s->b_hit0, &s->b_nrm, &s->b_link, &s->b_color, &s->b_shadow_lit};
+    if (which < 0 || which > 6) return fail(RT_ERR_INVALID, "bad array id");
+    const size_t el = which == 6 ? 1 : 16;
+    if (!b[which]->p || (first + count) * el > b[which]->bytes) return fail(RT_ERR_INVALID, "range outside the pool");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemcpy(out, (const char*)b[which]->p + first * el, count * el, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 int rt_sync(rt_scene* s) {
     if (!s) return fail(RT_ERR_INVALID, "scene is NULL");
     HIPCHK(hipSetDevice(s->device));

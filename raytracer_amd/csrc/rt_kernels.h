@@ -448,7 +448,7 @@ __device__ __forceinline__ void shade_ctx(const DScene& S, const DMaterial& mat,
         if (sin2T >= 1.0f) {
             c.tir = true;
         } else {
-            float cosT = __fsqrt_rn(1.0f - sin2T);
+            float cosT = sqrtf(1.0f - sin2T);
             c.Fr = fresnel_dielectric(cosI, cosT, etaI, etaT);
             c.wt = normalize((c.w0 * -1.0f) * eta + normal * (eta * cosI - cosT));
             c.refr_origin = c.x - normal * eps;

@@ -151,7 +151,7 @@ __device__ __forceinline__ bool sphere_test(const ActiveRay& r, float cx, float 
     float C = dot(oc, oc) - radius * radius;
     float delta = B * B - 4 * A * C;
     if (delta < 0.0f) return false;
-    float sq = __fsqrt_rn(delta);
+    float sq = sqrtf(delta);
     float t1 = (-B - sq) / (2 * A);
     float t2 = (-B + sq) / (2 * A);
     float t;

@@ -93,6 +93,7 @@ def host_lib():
         L.rth_scene_camera_name.argtypes = [C.c_void_p, C.c_int]
         L.rth_scene_set_camera_resolution.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.rth_scene_free.argtypes = [C.c_void_p]
+        L.rth_scene_set_max_depth.argtypes = [C.c_void_p, C.c_int]
         L.rth_last_error.restype = C.c_char_p
         L.rth_builder_new.restype = C.c_void_p
         L.rth_builder_free.argtypes = [C.c_void_p]
@@ -157,6 +158,9 @@ class HostScene:
     def set_camera_resolution(self, i, width, height, num_samples):
         if host_lib().rth_scene_set_camera_resolution(self._h, i, width, height, num_samples) != 0:
             raise RtError("bad camera resolution")
+
+    def set_max_depth(self, depth):
+        host_lib().rth_scene_set_max_depth(self._h, depth)
 
     def close(self):
         if self._h:

@@ -225,6 +225,12 @@ int rth_scene_set_camera_resolution(rth_scene* s, int i, int width, int height, 
     c.samples_per_side = (int)std::sqrt((double)num_samples);   // parser.cpp:411
     return RT_OK;
 }
+int rth_scene_set_max_depth(rth_scene* s, int d) {
+    if (!s) return RT_ERR_INVALID;
+    s->st.max_recursion_depth = d;
+    s->st.finalize();
+    return RT_OK;
+}
 void rth_scene_free(rth_scene* s) { delete s; }
 
 // ------------------------------------------------------------------ builder
