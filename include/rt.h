@@ -281,6 +281,21 @@ int rt_render_tile_device(rt_scene* s, const rt_camera_desc* cam,
                           void* d_rgb_out, size_t rgb_row_stride_bytes,
                           void* d_hit_id_out, rt_stats* stats, void* hip_stream);
 
+/* Multi-GPU load balancing: as rt_render_tile_device, but only the 8-pixel-high
+ * tile rows ty (counted from the top of the rectangle) with ty % row_parts ==
+ * row_part are rendered; all other bytes of the output buffers are left
+ * untouched.  GPU g of G calls it with (G, g) on its own replica of the scene
+ * and its own device framebuffer; the framebuffers are then merged (RCCL
+ * gather / peer copy of each GPU's rows).  Pixels are independent and seeded by
+ * their global coordinates (raytracer.cpp:44), so the merged image is
+ * byte-identical to a single-GPU render.  The reference's counterpart is the
+ * static OpenMP partition of the same loop (raytracer.cpp:40). */
+int rt_render_tile_rows_device(rt_scene* s, const rt_camera_desc* cam,
+                               int x0, int y0, int tile_w, int tile_h,
+                               int row_parts, int row_part,
+                               void* d_rgb_out, size_t rgb_row_stride_bytes,
+                               void* d_hit_id_out, rt_stats* stats, void* hip_stream);
+
 /* Debug aid: copy `count` entries of one array of the ray-record pool, as left
  * by the last render call, to host memory.  which: 0 ray0 (origin.xyz,time; 16 B),
  * 1 ray1 (direction.xyz,live; 16 B), 2 hit0 (t,kind_index,tri,-; 16 B),

@@ -409,8 +409,9 @@ void to_dcamera(const rt_camera_desc* c, DCamera& d) {
     d.dof = c->has_depth_of_field;
 }
 
-int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, int h, uint8_t* d_rgb, size_t stride,
-                uint32_t* d_hits, rt_stats* stats, hipStream_t st) {
+int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, int h, int row_parts, int row_part,
+                uint8_t* d_rgb, size_t stride, uint32_t* d_hits, rt_stats* stats, hipStream_t st) {
+    if (row_parts < 1 || row_part < 0 || row_part >= row_parts) return fail(RT_ERR_INVALID, "bad interleave %d/%d", row_part, row_parts);
     if (!sc || !cam) return fail(RT_ERR_INVALID, "NULL scene or camera");
     if (w <= 0 || h <= 0 || x0 < 0 || y0 < 0 || x0 + w > cam->image_width || y0 + h > cam->image_height)
         return fail(RT_ERR_INVALID, "tile [%d,%d %dx%d] outside the %dx%d image", x0, y0, w, h, cam->image_width, cam->image_height);
@@ -453,7 +454,8 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
     DCamera dc;
     to_dcamera(cam, dc);
     const float inv_n = 1.0f / N;   // raytracer.cpp:38
-    const int tiles_per_row = (w + 7) / 8, tile_rows = (h + 7) / 8;
+    const int tiles_per_row = (w + 7) / 8, tile_rows_all = (h + 7) / 8;
+    const int tile_rows = row_part < tile_rows_all ? (tile_rows_all - row_part + row_parts - 1) / row_parts : 0;
     const uint32_t total_tiles = (uint32_t)tiles_per_row * tile_rows;
     const Pool& P = sc->pool;
     // tiles per chunk: bounded by the chunk option, the record pool and the shadow pool
@@ -467,7 +469,7 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
     uint32_t tile = 0;
     while (tile < total_tiles) {
         const uint32_t nt = std::min(tiles_per_chunk, total_tiles - tile);
-        ChunkGeom g{x0, y0, w, h, tiles_per_row, tile, nt * 64u};
+        ChunkGeom g{x0, y0, w, h, tiles_per_row, tile, nt * 64u, row_parts, row_part};
         const uint32_t n_primary = g.n_idx * (uint32_t)N;
         k_init_chunk<<<1, 64, 0, st>>>(ctl, n_primary);
         if ((rc = tm.begin(TC_RAYGEN))) return rc;
@@ -616,7 +618,16 @@ int rt_render_tile_device(rt_scene* s, const rt_camera_desc* cam, int x0, int y0
                           size_t rgb_row_stride_bytes, void* d_hit_id_out, rt_stats* stats, void* hip_stream) {
     if (!s) return fail(RT_ERR_INVALID, "scene is NULL");
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
-    return render_impl(s, cam, x0, y0, tile_w, tile_h, (uint8_t*)d_rgb_out, rgb_row_stride_bytes, (uint32_t*)d_hit_id_out, stats, st);
+    return render_impl(s, cam, x0, y0, tile_w, tile_h, 1, 0, (uint8_t*)d_rgb_out, rgb_row_stride_bytes, (uint32_t*)d_hit_id_out, stats, st);
+}
+
+int rt_render_tile_rows_device(rt_scene* s, const rt_camera_desc* cam, int x0, int y0, int tile_w, int tile_h, int row_parts,
+                               int row_part, void* d_rgb_out, size_t rgb_row_stride_bytes, void* d_hit_id_out, rt_stats* stats,
+                               void* hip_stream) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is NULL");
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
+    return render_impl(s, cam, x0, y0, tile_w, tile_h, row_parts, row_part, (uint8_t*)d_rgb_out, rgb_row_stride_bytes,
+                       (uint32_t*)d_hit_id_out, stats, st);
 }
 
 int rt_render_tile(rt_scene* s, const rt_camera_desc* cam, int x0, int y0, int tile_w, int tile_h, uint8_t* rgb_out,
@@ -628,7 +639,7 @@ int rt_render_tile(rt_scene* s, const rt_camera_desc* cam, int x0, int y0, int t
     int rc = s->b_fb.ensure(fb_bytes);
     if (rc) return rc;
     if (hit_id_out && (rc = s->b_hits.ensure(hit_bytes))) return rc;
-    rc = render_impl(s, cam, x0, y0, tile_w, tile_h, (uint8_t*)s->b_fb.p, (size_t)tile_w * 3, hit_id_out ? (uint32_t*)s->b_hits.p : nullptr,
+    rc = render_impl(s, cam, x0, y0, tile_w, tile_h, 1, 0, (uint8_t*)s->b_fb.p, (size_t)tile_w * 3, hit_id_out ? (uint32_t*)s->b_hits.p : nullptr,
                      stats, s->stream);
     if (rc) return rc;
     HIPCHK(hipMemcpy2DAsync(rgb_out, rgb_row_stride_bytes, s->b_fb.p, (size_t)tile_w * 3, (size_t)tile_w * 3, tile_h,

@@ -51,11 +51,13 @@ struct ChunkGeom {
     int tiles_per_row;
     uint32_t tile_begin;     // first tile of this chunk
     uint32_t n_idx;          // 64 * tiles in this chunk
+    int row_parts, row_part; // only tile rows ty with ty % row_parts == row_part are rendered (multi-GPU interleave)
 };
 __device__ __forceinline__ bool idx_to_pixel(const ChunkGeom& g, uint32_t idx, int& px, int& py) {
     uint32_t tile = g.tile_begin + (idx >> 6);
     uint32_t in = idx & 63u;
-    int tx = (int)(tile % (uint32_t)g.tiles_per_row), ty = (int)(tile / (uint32_t)g.tiles_per_row);
+    int tx = (int)(tile % (uint32_t)g.tiles_per_row);
+    int ty = (int)(tile / (uint32_t)g.tiles_per_row) * g.row_parts + g.row_part;
     int lx = tx * 8 + (int)(in & 7u), ly = ty * 8 + (int)(in >> 3);
     px = g.x0 + lx;
     py = g.y0 + ly;

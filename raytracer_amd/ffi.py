@@ -297,6 +297,10 @@ def hip_lib():
                                      C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Stats)]
         L.rt_render_tile_device.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Stats), C.c_void_p]
+        L.rt_render_tile_rows_device.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Stats),
+                                                 C.c_void_p]
+        L.rt_debug_fetch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]
         L.rt_sync.argtypes = [C.c_void_p]
         L.rt_free_scene.argtypes = [C.c_void_p]
         L.rt_last_error.restype = C.c_char_p
@@ -340,6 +344,15 @@ class DeviceScene:
                                                C.c_void_p(d_hits_ptr) if d_hits_ptr else None,
                                                C.byref(stats) if stats is not None else None,
                                                C.c_void_p(stream) if stream else None))
+
+    def render_rows_device(self, cam, x0, y0, w, h, row_parts, row_part, d_rgb_ptr, row_stride, d_hits_ptr=None,
+                           stats=None, stream=None):
+        """rt_render_tile_rows_device: this GPU's interleaved share of the rectangle."""
+        _check(hip_lib().rt_render_tile_rows_device(self._h, C.byref(cam), x0, y0, w, h, row_parts, row_part,
+                                                    C.c_void_p(d_rgb_ptr), row_stride,
+                                                    C.c_void_p(d_hits_ptr) if d_hits_ptr else None,
+                                                    C.byref(stats) if stats is not None else None,
+                                                    C.c_void_p(stream) if stream else None))
 
     def sync(self):
         _check(hip_lib().rt_sync(self._h))
