@@ -8,3 +8,4 @@ from .ffi import (CameraDesc, DeviceScene, HostScene, Material, RtError, SceneBu
                   RT_KIND_MESH, RT_KIND_PLANE, RT_KIND_SPHERE, RT_KIND_TRIANGLE,
                   RT_MAT_CONDUCTOR, RT_MAT_DIELECTRIC, RT_MAT_MIRROR, RT_MAT_NONE,
                   hip_lib, host_lib, mat_mul, mat_rotation, mat_scaling, mat_translation)
+from . import multigpu, scenes  # noqa: E402,F401

@@ -1,0 +1,158 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against
+(a) the reference's own renders and hit identities (tests/golden), (b) the
+oracle on seeded synthetic scenes, (c) size-independent properties at the
+bench's full size.  Bars: images byte-exact (north_star allows 1 LSB on 99.9 %);
+primary hit ids identical (north_star allows 99.99 %)."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+GOLD = ["hw1_simple", "hw1_spheres_mirror", "hw1_cornellbox_recursive", "hw1_two_spheres", "hw1_spheres_with_plane",
+        "hw2_mirror_room", "hw2_metal_glass_plates", "hw2_two_berserkers", "hw2_ellipsoids", "hw2_simple_transform",
+        "hw3_spheres_dof", "hw3_cornellbox_boxes_dynamic"]
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import raytracer_amd
+    raytracer_amd.hip_lib()          # fails loudly if the extension is missing
+    assert raytracer_amd.hip_lib().rt_device_count() >= 1
+    return raytracer_amd
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_golden_reference_scene(rt, name):
+    hs = util.golden_scene(name)
+    cam = hs.camera(0)
+    ds = rt.DeviceScene(hs, 0)
+    rgb, hits = ds.render(cam, want_hits=True)
+    ds.close()
+    st = util.image_stats(rgb, util.golden_image(name))
+    ok = util.hit_ids_match(hits, util.golden_hits(name))
+    assert ok.mean() >= 0.9999, f"hit-id parity {ok.mean()}"
+    assert st["within1"] >= 0.999, st
+    assert ok.all() and st["exact"] == 1.0, (st, float(ok.mean()))   # the bar this build holds itself to
+
+
+def _vs_oracle(rt, spec, **opts):
+    from oracle import binding as ob
+    hs = spec.build()
+    cam = hs.camera(0)
+    ds = rt.DeviceScene(hs, 0)
+    for k, v in opts.items():
+        ds.set_option(k, v)
+    st = rt.Stats()
+    rgb, hits = ds.render(cam, want_hits=True, stats=st)
+    ds.close()
+    o_rgb, o_hits, ctr = ob.render(hs, cam, want_hits=True)
+    assert (hits == o_hits).all()
+    assert (rgb == o_rgb).all(), int((rgb != o_rgb).any(-1).sum())
+    assert st.rays_primary == ctr.rays_primary and st.rays_secondary == ctr.rays_secondary and st.rays_shadow == ctr.s_rays
+    return st
+
+
+def test_synthetic_mesh_vs_oracle(rt):
+    _vs_oracle(rt, rt.scenes.mesh_scene(grid=96, width=640, height=360))
+
+
+def test_synthetic_instances_depth6_vs_oracle(rt):
+    _vs_oracle(rt, rt.scenes.instanced_scene(grid=64, width=480, height=270))
+
+
+def test_synthetic_multisample_dof_vs_oracle(rt):
+    _vs_oracle(rt, rt.scenes.spheres_scene(200, 150, num_samples=16, dof=True))
+
+
+def test_ragged_sizes_and_tiny_images(rt):
+    """Edge tiles (w,h not multiples of 8), 1x1 and 1xN images."""
+    from oracle import binding as ob
+    for (w, h) in [(1, 1), (1, 17), (13, 1), (37, 29), (65, 9)]:
+        spec = rt.scenes.spheres_scene(w, h)
+        hs = spec.build()
+        cam = hs.camera(0)
+        ds = rt.DeviceScene(hs, 0)
+        rgb, hits = ds.render(cam, want_hits=True)
+        ds.close()
+        o_rgb, o_hits, _ = ob.render(hs, cam, want_hits=True)
+        assert (rgb == o_rgb).all() and (hits == o_hits).all(), (w, h)
+
+
+def test_chunking_and_pool_pressure_do_not_change_the_image(rt):
+    """Small chunks and a small record pool (forcing the overflow/retry path) give the same bytes."""
+    spec = rt.scenes.instanced_scene(grid=32, width=320, height=200)
+    hs = spec.build()
+    cam = hs.camera(0)
+    ds = rt.DeviceScene(hs, 0)
+    a, _ = ds.render(cam)
+    ds.close()
+    ds = rt.DeviceScene(hs, 0)
+    ds.set_option(rt.RT_OPT_POOL_RECORDS, 40000)
+    ds.set_option(rt.RT_OPT_CHUNK_SAMPLES, 4096)
+    st = rt.Stats()
+    b, _ = ds.render(cam, stats=st)
+    ds.close()
+    assert st.chunks > 4
+    assert (a == b).all()
+
+
+def test_tiles_and_interleaved_rows_stitch_to_the_full_frame(rt):
+    """Multi-GPU partition rehearsed on one GPU: windows and interleaved row bands
+    reproduce the single-call frame byte for byte (global-pixel seeding)."""
+    import torch
+    hs = util.golden_scene("hw1_cornellbox_recursive")
+    cam = hs.camera(0)
+    W, H = cam.image_width, cam.image_height
+    ds = rt.DeviceScene(hs, 0)
+    full, _ = ds.render(cam)
+    tile, _ = ds.render(cam, x0=123, y0=77, w=301, h=211)
+    assert (tile == full[77:288, 123:424]).all()
+    parts = 3
+    merged = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0")
+    for p in range(parts):
+        fb = torch.full((H, W, 3), 7, dtype=torch.uint8, device="cuda:0")
+        ds.render_rows_device(cam, 0, 0, W, H, parts, p, fb.data_ptr(), W * 3, stats=rt.Stats())
+        rows = rt.multigpu.rows_of(p, parts, H).to("cuda:0")
+        merged[rows] = fb[rows]
+        other = rt.multigpu.rows_of((p + 1) % parts, parts, H).to("cuda:0")
+        assert (fb[other] == 7).all()          # rows of other ranks are left untouched
+    ds.close()
+    assert (merged.cpu().numpy() == full).all()
+
+
+def test_full_size_properties_mesh1m(rt):
+    """BASELINE configs[1] at full size (1 002 528 triangles, 1920x1080): determinism,
+    tile independence, and exact agreement with the oracle on a window."""
+    from oracle import binding as ob
+    spec = rt.scenes.mesh_scene(709, 1920, 1080)
+    hs = spec.build()
+    cam = hs.camera(0)
+    ds = rt.DeviceScene(hs, 0)
+    st = rt.Stats()
+    a, ha = ds.render(cam, want_hits=True, stats=st)
+    b, hb = ds.render(cam, want_hits=True)
+    assert (a == b).all() and (ha == hb).all()                     # idempotent / deterministic
+    assert st.rays_primary == 1920 * 1080
+    hit = ha[..., 0] != 0xFFFFFFFF
+    assert st.rays_shadow == 2 * int(hit.sum())                    # 2 point lights per shaded hit, depth 0
+    x0, y0, w, h = 840, 470, 256, 160
+    win, hw = ds.render(cam, x0=x0, y0=y0, w=w, h=h, want_hits=True)
+    ds.close()
+    assert (win == a[y0:y0 + h, x0:x0 + w]).all() and (hw == ha[y0:y0 + h, x0:x0 + w]).all()
+    o_rgb, o_hits, _ = ob.render(hs, cam, x0=x0, y0=y0, w=w, h=h, want_hits=True)
+    assert (win == o_rgb).all() and (hw == o_hits).all()
+
+
+def test_errors_are_reported_not_thrown(rt):
+    hs = util.golden_scene("hw3_cornellbox_area")        # area light: RNG drawn while shading
+    ds = rt.DeviceScene(hs, 0)
+    with pytest.raises(rt.RtError):
+        ds.render(hs.camera(0))
+    cam = util.golden_scene("hw1_simple").camera(0)
+    ds2 = rt.DeviceScene(util.golden_scene("hw1_simple"), 0)
+    with pytest.raises(rt.RtError):
+        ds2.render(cam, x0=700, y0=0, w=200, h=10)         # outside the image
+    ds.close()
+    ds2.close()
