@@ -14,43 +14,52 @@
 #define RT_EPS_PARALLEL 1e-8f         // raytracer.h:12
 
 // ------------------------------------------------------------ link encoding
-// A link names the next thing to visit.  bit31 clear: index of a DNode (an
-// interior node of a reference BVH).  bit31 set: a leaf — index of the first
-// DTri (mesh level) or first DTopPrim slot (top level) — or a special value.
-#define RT_LINK_LEAF     0x80000000u
-#define RT_LINK_DONE     0xFFFFFFFFu   // empty stack at the top level / empty BVH
-#define RT_LINK_SENTINEL 0xFFFFFFFEu   // bottom of a mesh traversal's stack segment
-#define RT_LINK_INDEX(l) ((l) & 0x7FFFFFFFu)
+// A link names the next thing to visit.
+//   bit31 clear : index of a DNode4.
+//   bit31 set   : a leaf.  bits 30..26 = prim count (1..30; 31 = "big leaf", the
+//                 count is in DScene::big_leaves), bits 25..0 = index of the first
+//                 DTri (mesh level) or DTopPrim slot (top level).
+//   two reserved values mark the bottom of the stack segments.
+#define RT_LINK_LEAF      0x80000000u
+#define RT_LINK_DONE      0xFFFFFFFFu   // empty stack at the top level / empty BVH
+#define RT_LINK_SENTINEL  0xFFFFFFFEu   // bottom of a mesh traversal's stack segment
+#define RT_LINK_NONE      0xFFFFFFFDu   // "no slot hit" marker inside the node step
+#define RT_LEAF_FIRST(l)  ((l) & 0x03FFFFFFu)
+#define RT_LEAF_COUNT(l)  (((l) >> 26) & 31u)
+#define RT_LEAF_MAX_FIRST 0x03FFFFF0u
+#define RT_LEAF_BIG       31u
 
-// One interior node of a reference BVH (Bvh.h:39-49) holding BOTH children's
-// boxes, so one 64-byte fetch decides both descents.  64-byte aligned.
-//   a = lmin.xyz, lmax.x   b = lmax.yz, rmin.xy   c = rmin.z, rmax.xyz
-struct __attribute__((aligned(64))) DNode {
-    float4   a, b, c;
-    uint32_t llink, rlink, pad0, pad1;
+// Two levels of a reference BVH (Bvh.h:39-49) collapsed into one 128-byte
+// record: for a reference interior node n with children L, R the four slots are
+// L.left, L.right, R.left, R.right in that (= the reference's depth-first)
+// order; a child that is itself a leaf occupies its first slot and leaves the
+// second one empty (mask bit clear).  box k = f[6k .. 6k+5] = min.xyz, max.xyz.
+struct __attribute__((aligned(128))) DNode4 {
+    float    f[24];
+    uint32_t link[4];
+    uint32_t mask;
+    uint32_t pad[3];
 };
-static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
+static_assert(sizeof(DNode4) == 128, "DNode4 must be 128 bytes");
 
 // Leaf-ordered triangle record: position p of a mesh BVH's primIdx array
 // (raytracer.cpp:783-789 resolved at upload: primIdx -> prims[].faceIdx ->
 // faces[] -> vertex_data[]).  e1 = a-b, e2 = a-c are the first two columns of
 // the Cramer system (raytracer.cpp:902-903), computed once on the host with the
-// same FP32 subtraction.  `remaining` = triangles left in this leaf, this one
-// included.  48 bytes = three 16-byte loads.
-struct __attribute__((aligned(16))) DTri {
-    float ax, ay, az, e1x;
-    float e1y, e1z, e2x, e2y;
-    float e2z;
-    uint32_t face;        // faceIdx inside the mesh's face set
-    uint32_t remaining;
-    uint32_t pad;
+// same FP32 subtraction.  36 bytes.
+struct DTri {
+    float ax, ay, az, e1x, e1y, e1z, e2x, e2y, e2z;
 };
-static_assert(sizeof(DTri) == 48, "DTri is 48 bytes");
+static_assert(sizeof(DTri) == 36, "DTri is 36 bytes");
+
+struct DBigLeaf { uint32_t first, count; };   // leaves with more than 30 prims (unsplittable nodes)
 
 // Shading-side data of the same triangle slot (only read for the closest hit).
-struct __attribute__((aligned(8))) DTriShade {
+struct __attribute__((aligned(16))) DTriShade {
     float nx, ny, nz;     // Face::n_unit
     int32_t i0, i1, i2;   // 1-based vertex ids (smooth normals)
+    uint32_t face;        // faceIdx inside the mesh's face set (hit identity)
+    uint32_t pad;
 };
 
 // Object record shared by mesh instances, spheres and triangles.
@@ -87,7 +96,7 @@ struct DPlane { float nx, ny, nz, d; int32_t material_id; };
 struct DPointLight { float px, py, pz, ix, iy, iz; };
 
 struct DScene {
-    const DNode*      nodes;
+    const DNode4*     nodes;
     const DTri*       tris;
     const DTriShade*  tri_shade;
     const float4*     vnormals;      // vertex normal per vertex_data entry (w unused)
@@ -96,6 +105,8 @@ struct DScene {
     const DPlane*     planes;
     const DMaterial*  materials;
     const DPointLight* point_lights;
+    const DBigLeaf*   big_leaves;    // sorted by first; mesh and top-level leaves share the table (top entries have bit31 of first set)
+    uint32_t n_big_leaves;
     uint32_t n_planes, n_point_lights, n_materials;
     uint32_t top_root_link;
     float    top_rmin[3], top_rmax[3];

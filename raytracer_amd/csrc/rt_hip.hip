@@ -71,7 +71,7 @@ struct rt_scene {
     int blocks_closest = 0, blocks_shadow = 0;   // persistent grid sizes
 
     // device scene
-    DevBuf b_nodes, b_tris, b_tri_shade, b_vnormals, b_objects, b_top_prims, b_planes, b_materials, b_lights;
+    DevBuf b_big, b_nodes, b_tris, b_tri_shade, b_vnormals, b_objects, b_top_prims, b_planes, b_materials, b_lights;
     DScene ds{};
     bool has_reflective = false;      // any material with type != None
     bool needs_sequential_rng = false;   // area lights or rough reflective materials (RNG drawn while shading)
@@ -166,36 +166,80 @@ float mat_det3(const float* m) {
     return m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
 }
 
-// Re-layout of one reference BVH: every interior node becomes a DNode carrying
-// both children's boxes; leaves become links into the leaf-ordered prim array.
+// Re-layout of one reference BVH into DNode4 records (two reference levels per
+// record, slots in the reference's depth-first order); leaves become links into
+// the leaf-ordered prim array, with their prim count in the link.
 struct BvhLayout {
     uint32_t root_link = RT_LINK_DONE;
     float rmin[3] = {0, 0, 0}, rmax[3] = {0, 0, 0};
 };
-BvhLayout layout_bvh(const rt_bvh_node* nodes, uint32_t count, uint32_t leaf_base, std::vector<DNode>& out) {
+struct BvhBuilder4 {
+    const rt_bvh_node* nodes;
+    uint32_t leaf_base;
+    bool top;
+    std::vector<DNode4>& out;
+    std::vector<DBigLeaf>& big;
+
+    uint32_t leaf_link(const rt_bvh_node& n) {
+        const uint32_t first = leaf_base + (uint32_t)n.left_or_first;
+        uint32_t code = (uint32_t)n.prim_count;
+        if (code > 30) {
+            big.push_back(DBigLeaf{first | (top ? 0x80000000u : 0u), (uint32_t)n.prim_count});
+            code = RT_LEAF_BIG;
+        }
+        return RT_LINK_LEAF | (code << 26) | first;
+    }
+    // iterative (an unsplittable-heavy tree can be deep): work items are reference interior nodes
+    uint32_t build(uint32_t root) {
+        struct Item { uint32_t ref_node, slot; };
+        std::vector<Item> work;
+        const uint32_t root_slot = (uint32_t)out.size();
+        out.emplace_back();
+        work.push_back({root, root_slot});
+        while (!work.empty()) {
+            Item it = work.back();
+            work.pop_back();
+            DNode4 d;
+            std::memset(&d, 0, sizeof(d));
+            for (int k = 0; k < 4; k++) d.link[k] = RT_LINK_DONE;
+            int s = 0;
+            auto put = [&](int slot, uint32_t ref) {
+                const rt_bvh_node& c = nodes[ref];
+                float* f = d.f + 6 * slot;
+                f[0] = c.bmin[0]; f[1] = c.bmin[1]; f[2] = c.bmin[2]; f[3] = c.bmax[0]; f[4] = c.bmax[1]; f[5] = c.bmax[2];
+                d.mask |= 1u << slot;
+                if (c.prim_count > 0) {
+                    d.link[slot] = leaf_link(c);
+                } else {
+                    const uint32_t ns = (uint32_t)out.size();
+                    out.emplace_back();
+                    d.link[slot] = ns;
+                    work.push_back({ref, ns});
+                }
+            };
+            const uint32_t L = (uint32_t)nodes[it.ref_node].left_or_first;
+            for (uint32_t child : {L, L + 1}) {
+                const rt_bvh_node& c = nodes[child];
+                if (c.prim_count > 0) {
+                    put(s, child);          // a leaf child keeps one slot; its sibling slot stays empty
+                } else {
+                    put(s, (uint32_t)c.left_or_first);
+                    put(s + 1, (uint32_t)c.left_or_first + 1);
+                }
+                s += 2;
+            }
+            // slot 0 must be valid for the device's fast path; it is, since the left child always fills slot 0
+            out[it.slot] = d;
+        }
+        return root_slot;
+    }
+};
+BvhLayout layout_bvh(const rt_bvh_node* nodes, uint32_t count, uint32_t leaf_base, bool top, std::vector<DNode4>& out,
+                     std::vector<DBigLeaf>& big) {
     BvhLayout L;
     if (count == 0) return L;
-    std::vector<uint32_t> slot(count, 0);
-    uint32_t base = (uint32_t)out.size(), n_int = 0;
-    for (uint32_t i = 0; i < count; i++)
-        if (nodes[i].prim_count == 0) slot[i] = base + n_int++;
-    auto link_of = [&](uint32_t i) -> uint32_t {
-        return nodes[i].prim_count > 0 ? (RT_LINK_LEAF | (leaf_base + (uint32_t)nodes[i].left_or_first)) : slot[i];
-    };
-    out.resize(base + n_int);
-    for (uint32_t i = 0; i < count; i++) {
-        if (nodes[i].prim_count != 0) continue;
-        const rt_bvh_node& l = nodes[nodes[i].left_or_first];
-        const rt_bvh_node& r = nodes[nodes[i].left_or_first + 1];
-        DNode& d = out[slot[i]];
-        d.a = make_float4(l.bmin[0], l.bmin[1], l.bmin[2], l.bmax[0]);
-        d.b = make_float4(l.bmax[1], l.bmax[2], r.bmin[0], r.bmin[1]);
-        d.c = make_float4(r.bmin[2], r.bmax[0], r.bmax[1], r.bmax[2]);
-        d.llink = link_of((uint32_t)nodes[i].left_or_first);
-        d.rlink = link_of((uint32_t)nodes[i].left_or_first + 1);
-        d.pad0 = d.pad1 = 0;
-    }
-    L.root_link = link_of(0);
+    BvhBuilder4 b{nodes, leaf_base, top, out, big};
+    L.root_link = nodes[0].prim_count > 0 ? b.leaf_link(nodes[0]) : b.build(0);
     std::memcpy(L.rmin, nodes[0].bmin, 12);
     std::memcpy(L.rmax, nodes[0].bmax, 12);
     return L;
@@ -213,7 +257,8 @@ void fill_object_common(DObject& o, uint32_t flags, const float* M, const float*
 }
 
 int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
-    std::vector<DNode> nodes;
+    std::vector<DNode4> nodes;
+    std::vector<DBigLeaf> big;
     std::vector<DTri> tris(s->n_mesh_prims);
     std::vector<DTriShade> tshade(s->n_mesh_prims);
 
@@ -221,7 +266,7 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
     std::vector<BvhLayout> mesh_layout(s->n_mesh_bvhs);
     for (uint32_t b = 0; b < s->n_mesh_bvhs; b++) {
         const rt_mesh_bvh& mb = s->mesh_bvhs[b];
-        mesh_layout[b] = layout_bvh(s->mesh_nodes + mb.node_offset, mb.node_count, mb.prim_offset, nodes);
+        mesh_layout[b] = layout_bvh(s->mesh_nodes + mb.node_offset, mb.node_count, mb.prim_offset, false, nodes, big);
         for (uint32_t p = 0; p < mb.prim_count; p++) {
             const uint32_t fi = s->mesh_prim_face[mb.prim_offset + p];
             const rt_face& f = s->faces[mb.face_offset + fi];
@@ -232,16 +277,11 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
             t.ax = a[0]; t.ay = a[1]; t.az = a[2];
             t.e1x = a[0] - bb[0]; t.e1y = a[1] - bb[1]; t.e1z = a[2] - bb[2];   // col_A0, raytracer.cpp:902
             t.e2x = a[0] - c[0];  t.e2y = a[1] - c[1];  t.e2z = a[2] - c[2];    // col_A1, raytracer.cpp:903
-            t.face = fi;
-            t.remaining = 1;
-            t.pad = 0;
             DTriShade& ts = tshade[mb.prim_offset + p];
+            ts.face = fi;
+            ts.pad = 0;
             ts.nx = f.n_unit[0]; ts.ny = f.n_unit[1]; ts.nz = f.n_unit[2];
             ts.i0 = f.i0; ts.i1 = f.i1; ts.i2 = f.i2;
-        }
-        for (uint32_t i = 0; i < mb.node_count; i++) {
-            const rt_bvh_node& n = s->mesh_nodes[mb.node_offset + i];
-            for (int32_t k = 0; k < n.prim_count; k++) tris[mb.prim_offset + n.left_or_first + k].remaining = (uint32_t)(n.prim_count - k);
         }
     }
 
@@ -293,8 +333,11 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
         const rt_bvh_node& n = s->top_nodes[i];
         for (int32_t k = 0; k < n.prim_count; k++) top[n.left_or_first + k].remaining = (uint32_t)(n.prim_count - k);
     }
-    BvhLayout TL = layout_bvh(s->top_nodes, s->n_top_prims ? s->n_top_nodes : 0, 0, nodes);
-    if (nodes.size() >= 0x7FFFFFF0u || tris.size() >= 0x7FFFFFF0u) return fail(RT_ERR_UNSUPPORTED, "scene too large for 31-bit links");
+    BvhLayout TL = layout_bvh(s->top_nodes, s->n_top_prims ? s->n_top_nodes : 0, 0, true, nodes, big);
+    if (nodes.size() >= 0x7FFFFFF0u || tris.size() >= RT_LEAF_MAX_FIRST || top.size() >= RT_LEAF_MAX_FIRST)
+        return fail(RT_ERR_UNSUPPORTED, "scene too large for the link encoding (2^26 leaf prims)");
+    std::sort(big.begin(), big.end(), [](const DBigLeaf& a, const DBigLeaf& b) { return a.first < b.first; });
+    if (big.empty()) big.push_back(DBigLeaf{0, 0});
 
     std::vector<float4> vn(s->n_vertices);
     for (uint32_t i = 0; i < s->n_vertices; i++)
@@ -332,11 +375,13 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
     int rc;
     if ((rc = upload_vec(sc->b_nodes, nodes)) || (rc = upload_vec(sc->b_tris, tris)) || (rc = upload_vec(sc->b_tri_shade, tshade)) ||
         (rc = upload_vec(sc->b_vnormals, vn)) || (rc = upload_vec(sc->b_objects, objects)) || (rc = upload_vec(sc->b_top_prims, top)) ||
-        (rc = upload_vec(sc->b_planes, planes)) || (rc = upload_vec(sc->b_materials, mats)) || (rc = upload_vec(sc->b_lights, lights)))
+        (rc = upload_vec(sc->b_big, big)) || (rc = upload_vec(sc->b_planes, planes)) || (rc = upload_vec(sc->b_materials, mats)) || (rc = upload_vec(sc->b_lights, lights)))
         return rc;
 
     DScene& D = sc->ds;
-    D.nodes = (const DNode*)sc->b_nodes.p;
+    D.nodes = (const DNode4*)sc->b_nodes.p;
+    D.big_leaves = (const DBigLeaf*)sc->b_big.p;
+    D.n_big_leaves = (uint32_t)big.size();
     D.tris = (const DTri*)sc->b_tris.p;
     D.tri_shade = (const DTriShade*)sc->b_tri_shade.p;
     D.vnormals = (const float4*)sc->b_vnormals.p;
@@ -501,7 +546,7 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         for (int d = D; d >= 0; d--) k_combine<<<grid_flat, 256, 0, st>>>(sc->ds, P, ctl, d);
         if ((rc = tm.end())) return rc;
         if ((rc = tm.begin(TC_RESOLVE))) return rc;
-        k_resolve<<<(g.n_idx + 255) / 256, 256, 0, st>>>(dc, g, P, sc->ds.tris, inv_n, d_rgb, stride, d_hits);
+        k_resolve<<<(g.n_idx + 255) / 256, 256, 0, st>>>(dc, g, P, sc->ds.tri_shade, inv_n, d_rgb, stride, d_hits);
         if ((rc = tm.end())) return rc;
         HIPCHK(hipGetLastError());
         chunks++;
@@ -672,7 +717,7 @@ void rt_free_scene(rt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    for (DevBuf* b : {&s->b_nodes, &s->b_tris, &s->b_tri_shade, &s->b_vnormals, &s->b_objects, &s->b_top_prims, &s->b_planes,
+    for (DevBuf* b : {&s->b_big, &s->b_nodes, &s->b_tris, &s->b_tri_shade, &s->b_vnormals, &s->b_objects, &s->b_top_prims, &s->b_planes,
                       &s->b_materials, &s->b_lights, &s->b_ray0, &s->b_ray1, &s->b_hit0, &s->b_hit1, &s->b_nrm, &s->b_link,
                       &s->b_color, &s->b_shadow_rec, &s->b_shadow_lit, &s->b_ctl, &s->b_spill, &s->b_mt, &s->b_fb, &s->b_hits})
         b->release();

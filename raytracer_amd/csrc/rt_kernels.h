@@ -699,7 +699,7 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) {   // Math
 }
 
 // raytracer.cpp:77-85: sum the samples in order, scale, clamp, truncate.
-__global__ void __launch_bounds__(256) k_resolve(DCamera cam, ChunkGeom g, Pool P, const DTri* tris, float inv_n,
+__global__ void __launch_bounds__(256) k_resolve(DCamera cam, ChunkGeom g, Pool P, const DTriShade* tri_shade, float inv_n,
                                                  uint8_t* rgb, size_t row_stride, uint32_t* hit_ids) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= g.n_idx) return;
@@ -722,7 +722,7 @@ __global__ void __launch_bounds__(256) k_resolve(DCamera cam, ChunkGeom g, Pool 
         uint32_t w0 = 0xFFFFFFFFu, w1 = 0xFFFFFFFFu;
         if (h0.y != 0xFFFFFFFFu) {
             w0 = h0.y;
-            w1 = ((h0.y >> 28) == RT_KIND_MESH) ? tris[h0.z].face : 0u;
+            w1 = ((h0.y >> 28) == RT_KIND_MESH) ? tri_shade[h0.z].face : 0u;
         }
         uint32_t* ho = hit_ids + ((size_t)ly * g.w + lx) * 2;
         ho[0] = w0;

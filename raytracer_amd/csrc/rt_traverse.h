@@ -8,15 +8,26 @@
 //   IntersectsTriangle_Bary raytracer.cpp:896-947, IntersectSphere :949-980
 //
 // Differences in FORM, none in result:
-//   * an interior node's record holds both children's boxes, so both are tested
-//     when the parent is visited.  The left child is what the reference pops
-//     next, with the same minT, so its test is the reference's test.  The right
-//     child is popped by the reference only after the whole left subtree; its
-//     box entry distance tEnter is kept on the stack and re-checked against the
-//     then-current minT at pop time.  Since IntersectAABB's verdict is
+//   * one node record holds the boxes of the four GRANDCHILDREN of a reference
+//     interior node (two levels collapsed), in the reference's depth-first
+//     order, and all four are tested when the record is visited.  The first hit
+//     slot is what the reference reaches next with the same minT.  Every other
+//     hit slot is reached by the reference only after the subtrees before it;
+//     its box entry distance tEnter is kept on the stack and re-checked against
+//     the then-current minT at pop time.  Since IntersectAABB's verdict is
 //     "min(minT, exit) < enter  or  (enter == 0 and min(minT, exit) <= 0)" and
 //     the box was a hit at push time, the pop-time verdict is exactly
-//     "minT < tEnter or (tEnter == 0 and minT <= 0)".
+//     "minT < tEnter or (tEnter == 0 and minT <= 0)".  The intermediate node
+//     between a record and its slots needs no test of its own: its box contains
+//     the slot's box, every slab operation is monotone under rounding, and the
+//     reference tests parent and child with the same minT (no primitive test in
+//     between), so "child box hit" implies "parent box hit" bit for bit; and a
+//     parent whose children all miss has no side effect in the reference.
+//   * a direction component that is exactly 0 takes 1/d = +inf instead of the
+//     reference's separate branch (raytracer.cpp:834-838): (b-o)*inf is -inf,
+//     NaN or +inf for o inside, on, or outside a face, and NaN operands are
+//     ignored by the reference's own std::max/std::min argument order, which
+//     reproduces "miss iff o < min or o > max" exactly, branch-free.
 //   * both BVH levels run in ONE loop (a lane switches its active ray to object
 //     space and back), so lanes at different levels share the node-fetch /
 //     box-test instructions instead of serialising nested loops.
@@ -72,53 +83,36 @@ struct TraceStack {
 // The ray a lane is currently traversing with (world or object space).
 struct ActiveRay {
     float ox, oy, oz, dx, dy, dz;
-    float ix, iy, iz;     // 1.0f / d (IEEE), unused where d == 0
-    uint32_t zmask;       // bit a set: d[a] == 0 (raytracer.cpp:821,841,861 else-branches)
+    float ix, iy, iz;     // 1.0f / d (IEEE); +inf where d == 0 (see file header)
     __device__ __forceinline__ void set(V3 o, V3 d) {
         ox = o.x; oy = o.y; oz = o.z; dx = d.x; dy = d.y; dz = d.z;
-        ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z;
-        zmask = (d.x == 0.0f ? 1u : 0u) | (d.y == 0.0f ? 2u : 0u) | (d.z == 0.0f ? 4u : 0u);
+        ix = (d.x == 0.0f) ? RT_INF : 1.0f / d.x;
+        iy = (d.y == 0.0f) ? RT_INF : 1.0f / d.y;
+        iz = (d.z == 0.0f) ? RT_INF : 1.0f / d.z;
     }
 };
 
-// One axis of IntersectAABB (raytracer.cpp:821-838).  std::max(a,b) = a<b?b:a
-// and std::min(a,b) = b<a?b:a keep the first argument when the second is NaN.
-__device__ __forceinline__ void slab(float bmin, float bmax, float o, float inv, bool dzero, float& tMin, float& tMax) {
-    float lo, hi;
-    if (!dzero) {
-        float t0 = (bmin - o) * inv;
-        float t1 = (bmax - o) * inv;
-        bool sw = t1 < t0;
-        lo = sw ? t1 : t0;
-        hi = sw ? t0 : t1;
-    } else {
-        bool outside = (o < bmin) || (o > bmax);
-        lo = outside ? RT_INF : -RT_INF;
-        hi = outside ? -RT_INF : RT_INF;
-    }
-    tMin = (tMin < lo) ? lo : tMin;
-    tMax = (hi < tMax) ? hi : tMax;
-}
-
-// IntersectAABB verdict + entry distance.  The per-axis early returns of the
-// reference are equivalent to one final test because tMin only grows and tMax
-// only shrinks; the trailing `tHit > minT` test (raytracer.cpp:889) can never
-// fire once tMax <= minT and tMin <= tMax.
+// IntersectAABB (raytracer.cpp:815-894) verdict + entry distance, branch-free.
+// Per axis: t0,t1, swapped iff t1 < t0 (as the reference's explicit swap: a NaN
+// never swaps); tMin = std::max(tMin, lo), tMax = std::min(tMax, hi) keep their
+// first argument when the second is NaN, which is what fmaxf/fminf (v_max_f32 /
+// v_min_f32) do since tMin/tMax themselves are never NaN.  The per-axis early
+// returns equal one final test because tMin only grows and tMax only shrinks;
+// "hit" = !(tMax < tMin) && !(tMin == 0 && tMax <= 0) = (tMin <= tMax) && (tMax > 0);
+// the trailing `tHit > minT` test (raytracer.cpp:889) cannot fire once tMax <= minT.
 __device__ __forceinline__ bool box_test(const ActiveRay& r, float mnx, float mny, float mnz, float mxx, float mxy,
                                          float mxz, float tmax, float& tEnter) {
-    float tMin = 0.0f, tMax = tmax;
-    if (r.zmask == 0) {
-        slab(mnx, mxx, r.ox, r.ix, false, tMin, tMax);
-        slab(mny, mxy, r.oy, r.iy, false, tMin, tMax);
-        slab(mnz, mxz, r.oz, r.iz, false, tMin, tMax);
-    } else {
-        slab(mnx, mxx, r.ox, r.ix, (r.zmask & 1u) != 0, tMin, tMax);
-        slab(mny, mxy, r.oy, r.iy, (r.zmask & 2u) != 0, tMin, tMax);
-        slab(mnz, mxz, r.oz, r.iz, (r.zmask & 4u) != 0, tMin, tMax);
-    }
+    const float ax = (mnx - r.ox) * r.ix, bx = (mxx - r.ox) * r.ix;
+    const float ay = (mny - r.oy) * r.iy, by = (mxy - r.oy) * r.iy;
+    const float az = (mnz - r.oz) * r.iz, bz = (mxz - r.oz) * r.iz;
+    const bool sx = bx < ax, sy = by < ay, sz = bz < az;
+    const float lox = sx ? bx : ax, hix = sx ? ax : bx;
+    const float loy = sy ? by : ay, hiy = sy ? ay : by;
+    const float loz = sz ? bz : az, hiz = sz ? az : bz;
+    const float tMin = fmaxf(fmaxf(fmaxf(0.0f, lox), loy), loz);
+    const float tMax = fminf(fminf(fminf(tmax, hix), hiy), hiz);
     tEnter = tMin;
-    bool miss = (tMax < tMin) || (!(tMin > 0.0f) && tMax <= 0.0f);
-    return !miss;
+    return (tMin <= tMax) && (tMax > 0.0f);
 }
 
 // IntersectsTriangle_Bary, raytracer.cpp:896-947, with col_A0/col_A1 preloaded.
@@ -208,6 +202,19 @@ __device__ __forceinline__ float world_t(const DObject& ob, V3 ro, float time, V
     return vlen(worldHit - ro);
 }
 
+__device__ __forceinline__ uint32_t leaf_count(const DScene& S, uint32_t link, bool top) {
+    uint32_t c = RT_LEAF_COUNT(link);
+    if (c != RT_LEAF_BIG) return c;
+    // unsplittable node with more than 30 prims (raytracer.cpp:183,317): binary search the side table
+    const uint32_t key = RT_LEAF_FIRST(link) | (top ? 0x80000000u : 0u);
+    uint32_t lo = 0, hi = S.n_big_leaves;
+    while (lo + 1 < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (S.big_leaves[mid].first <= key) lo = mid; else hi = mid;
+    }
+    return S.big_leaves[lo].count;
+}
+
 // Traverse the scene's BVHs.  On entry `minT`/`has`/`out` carry the result of
 // the plane loop (FindClosestHit raytracer.cpp:423-435 / InShadow :1022-1028).
 // ANYHIT: returns true at the first accepted hit (InShadow).  Otherwise updates
@@ -223,7 +230,6 @@ __device__ bool traverse(const DScene& S, V3 ro, V3 rd, float time, float minT, 
     uint32_t top_slot = 0, top_remaining = 0;
     // state of the mesh traversal in flight
     uint32_t cur_obj = 0;
-    V3 obj_o = ro, obj_d = rd;
     bool mesh_found = false;
     uint32_t mesh_tri = 0;
     float mesh_beta = 0.f, mesh_gamma = 0.f;
@@ -237,33 +243,36 @@ __device__ bool traverse(const DScene& S, V3 ro, V3 rd, float time, float minT, 
     }
 
     for (;;) {
-        // ---- interior nodes of either level
+        // ---- collapsed interior records of either level
         while (!(cur & RT_LINK_LEAF)) {
-            const DNode* n = &S.nodes[cur];
-            const float4 a = n->a, b = n->b, c = n->c;
-            const uint32_t ll = n->llink, rl = n->rlink;
-            float tl, tr;
-            const bool hl = box_test(ar, a.x, a.y, a.z, a.w, b.x, b.y, tmax, tl);
-            const bool hr = box_test(ar, b.z, b.w, c.x, c.y, c.z, c.w, tmax, tr);
-            if (hl) {
-                if (hr) st.push(rl, tr);
-                cur = ll;
-            } else if (hr) {
-                cur = rl;
-            } else {
-                cur = st.pop(tmax);
-            }
+            const float4* p = reinterpret_cast<const float4*>(&S.nodes[cur]);
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
+            const uint4 lk = reinterpret_cast<const uint4*>(p)[6];
+            const uint32_t mask = reinterpret_cast<const uint32_t*>(p)[28];
+            float t0, t1, t2, t3;
+            const bool h0 = box_test(ar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax, t0);                 // slot 0 is always valid
+            const bool h1 = box_test(ar, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax, t1) && (mask & 2u);
+            const bool h2 = box_test(ar, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, tmax, t2) && (mask & 4u);
+            const bool h3 = box_test(ar, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, tmax, t3) && (mask & 8u);
+            // visit order = slot order; later hits are pushed last-first so they pop in order
+            uint32_t nx = RT_LINK_NONE;
+            float tn = 0.f;
+            if (h3) { nx = lk.w; tn = t3; }
+            if (h2) { if (nx != RT_LINK_NONE) st.push(nx, tn); nx = lk.z; tn = t2; }
+            if (h1) { if (nx != RT_LINK_NONE) st.push(nx, tn); nx = lk.y; tn = t1; }
+            if (h0) { if (nx != RT_LINK_NONE) st.push(nx, tn); nx = lk.x; }
+            cur = (nx != RT_LINK_NONE) ? nx : st.pop(tmax);
         }
 
         if (in_mesh) {
             if (cur != RT_LINK_SENTINEL) {
                 // ---- mesh leaf: triangles in primIdx order (raytracer.cpp:781-798)
-                uint32_t ti = RT_LINK_INDEX(cur);
-                for (;;) {
-                    const float4* tp = reinterpret_cast<const float4*>(&S.tris[ti]);
-                    const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                uint32_t ti = RT_LEAF_FIRST(cur);
+                uint32_t n = leaf_count(S, cur, false);
+                for (; n != 0; n--, ti++) {
+                    const float* tp = reinterpret_cast<const float*>(&S.tris[ti]);
                     float t, bb, gg;
-                    if (tri_test(ar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, tmax, t, bb, gg)) {
+                    if (tri_test(ar, tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6], tp[7], tp[8], tmax, t, bb, gg)) {
                         tmax = t;
                         mesh_found = true;
                         mesh_tri = ti;
@@ -275,8 +284,6 @@ __device__ bool traverse(const DScene& S, V3 ro, V3 rd, float time, float minT, 
                             if (!(S.objects[cur_obj].flags & RT_OBJ_HAS_TRANSFORM)) return true;
                         }
                     }
-                    if (__float_as_uint(q2.z) <= 1u) break;   // remaining
-                    ti++;
                 }
                 cur = st.pop(tmax);
                 continue;
@@ -285,7 +292,7 @@ __device__ bool traverse(const DScene& S, V3 ro, V3 rd, float time, float minT, 
             in_mesh = false;
             if (mesh_found) {
                 const DObject& ob = S.objects[cur_obj];
-                float wt = world_t(ob, ro, time, obj_o, obj_d, tmax);
+                float wt = world_t(ob, ro, time, mk(ar.ox, ar.oy, ar.oz), mk(ar.dx, ar.dy, ar.dz), tmax);
                 if (wt < minT) {
                     if (ANYHIT) return true;
                     minT = wt;
@@ -300,8 +307,8 @@ __device__ bool traverse(const DScene& S, V3 ro, V3 rd, float time, float minT, 
             tmax = minT;
         } else {
             if (cur == RT_LINK_DONE) break;
-            top_slot = RT_LINK_INDEX(cur);
-            top_remaining = 1;   // refined from the first record below
+            top_slot = RT_LEAF_FIRST(cur);
+            top_remaining = leaf_count(S, cur, true);
         }
 
         // ---- prims of the current top-level leaf, in order (raytracer.cpp:548-745)
@@ -309,7 +316,7 @@ __device__ bool traverse(const DScene& S, V3 ro, V3 rd, float time, float minT, 
         while (top_remaining != 0) {
             const DTopPrim tp = S.top_prims[top_slot];
             top_slot++;
-            top_remaining = tp.remaining - 1;
+            top_remaining--;
             const DObject& ob = S.objects[tp.obj];
             V3 to, td;
             float testMinT;
@@ -322,8 +329,6 @@ __device__ bool traverse(const DScene& S, V3 ro, V3 rd, float time, float minT, 
                 if (!box_test(mr, ob.rminx, ob.rminy, ob.rminz, ob.rmaxx, ob.rmaxy, ob.rmaxz, testMinT, te)) continue;
                 ar = mr;
                 tmax = testMinT;
-                obj_o = to;
-                obj_d = td;
                 cur_obj = tp.obj;
                 cur_kind_index = (RT_KIND_MESH << 28) | tp.index;
                 mesh_found = false;
