@@ -20,6 +20,10 @@ hip: $(PKG)/librt_hip.so
 $(PKG)/librt_hip.so: $(wildcard $(PKG)/csrc/*.hip $(PKG)/csrc/*.h) include/rt.h
 	$(HIPCC) $(HIPFLAGS) -I$(PKG)/csrc -o $@ $(PKG)/csrc/rt_hip.hip
 
+# experiment build: make variant NAME=foo DEFS="-DRT_STACK_LDS=8"  -> raytracer_amd/librt_hip_foo.so (RT_HIP_SO selects it)
+variant:
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -I$(PKG)/csrc -o $(PKG)/librt_hip_$(NAME).so $(PKG)/csrc/rt_hip.hip
+
 oracle:
 	$(MAKE) -C oracle all
 

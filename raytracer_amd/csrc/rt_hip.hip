@@ -575,6 +575,16 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         if (sc->h_ctl->overflow & 4u) return fail(RT_ERR_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
         if (sc->h_ctl->overflow & 3u) return fail(RT_ERR_OVERFLOW, "ray pool overflow");
     }
+#ifdef RT_TRACE_STATS
+    if (want_sync) {
+        const unsigned long long* d = sc->h_ctl->dbg;
+        fprintf(stderr, "[rt stats] closest: wave_node_steps=%llu lane_node_steps=%llu (util %.3f) wave_tri_steps=%llu lane_tri_steps=%llu (util %.3f) "
+                        "outer=%llu rays=%llu | per ray: node %.1f tri %.2f | per 64-ray batch: wave node steps %.1f tri steps %.1f outer %.1f\n",
+                d[0], d[1], d[0] ? d[1] / (64.0 * d[0]) : 0.0, d[2], d[3], d[2] ? d[3] / (64.0 * d[2]) : 0.0, d[4], d[5],
+                d[5] ? (double)d[1] / d[5] : 0.0, d[5] ? (double)d[3] / d[5] : 0.0, d[5] ? 64.0 * d[0] / d[5] : 0.0,
+                d[5] ? 64.0 * d[2] / d[5] : 0.0, d[5] ? 64.0 * d[4] / d[5] : 0.0);
+    }
+#endif
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         stats->rays_primary = sc->h_ctl->rays_primary;

@@ -41,6 +41,7 @@ struct Control {
     uint32_t overflow;                 // 1: record pool, 2: shadow pool, 4: traversal stack
     uint32_t pad;
     unsigned long long rays_primary, rays_secondary, rays_shadow;
+    unsigned long long dbg[16];        // RT_TRACE_STATS builds only
 };
 
 // ----------------------------------------------------------------- pixel order
@@ -279,25 +280,36 @@ struct WaveWork {
     }
 };
 
+// LDS per wave: RT_STACK_LDS stack entries + RT_LEAF_QUEUE postponed leaves, 8 bytes each per lane.
+#define RT_LDS_ENTRIES (RT_STACK_LDS + RT_LEAF_QUEUE)
 __device__ __forceinline__ TraceStack make_stack(uint32_t* s_link, float* s_t, uint2* spill, const WaveWork& ww) {
     TraceStack st;
-    st.lds_link = s_link + ww.wave * (RT_STACK_LDS * 64);
-    st.lds_t = s_t + ww.wave * (RT_STACK_LDS * 64);
+    st.lds_link = s_link + ww.wave * (RT_LDS_ENTRIES * 64);
+    st.lds_t = s_t + ww.wave * (RT_LDS_ENTRIES * 64);
+    st.q_link = st.lds_link + RT_STACK_LDS * 64;
+    st.q_t = st.lds_t + RT_STACK_LDS * 64;
     size_t wave_slot = (size_t)blockIdx.x * (RT_TRACE_BLOCK / 64) + ww.wave;
     st.spill = spill + wave_slot * (size_t)((RT_STACK_MAX - RT_STACK_LDS) * 64);
     st.lane = ww.lane;
     st.sp = 0;
     st.overflow = 0;
+#ifdef RT_TRACE_STATS
+    st.acc = nullptr;
+#endif
     return st;
 }
 
 // FindClosestHit's search part (raytracer.cpp:405-444) for generation `gen`.
-__global__ void __launch_bounds__(RT_TRACE_BLOCK) k_trace_closest(DScene S, Pool P, Control* ctl, int gen, uint2* spill) {
-    __shared__ uint32_t s_link[(RT_TRACE_BLOCK / 64) * RT_STACK_LDS * 64];
-    __shared__ float s_t[(RT_TRACE_BLOCK / 64) * RT_STACK_LDS * 64];
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_closest(DScene S, Pool P, Control* ctl, int gen, uint2* spill) {
+    __shared__ uint32_t s_link[(RT_TRACE_BLOCK / 64) * RT_LDS_ENTRIES * 64];
+    __shared__ float s_t[(RT_TRACE_BLOCK / 64) * RT_LDS_ENTRIES * 64];
     WaveWork ww;
     TraceStack st = make_stack(s_link, s_t, spill, ww);
     const uint32_t begin = ctl->gstart[gen], end = ctl->gstart[gen + 1];
+#ifdef RT_TRACE_STATS
+    TraceStatsAcc acc = {};
+    st.acc = &acc;
+#endif
     unsigned long long traced = 0;   // wave-uniform
     for (;;) {
         // every lane of the wave reaches this point together: the body below is
@@ -337,16 +349,26 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK) k_trace_closest(DScene S, Pool
         }
     }
     if (st.overflow) atomicOr(&ctl->overflow, 4u);
+#ifdef RT_TRACE_STATS
+    atomicAdd(&ctl->dbg[0], acc.wave_node_steps); atomicAdd(&ctl->dbg[1], acc.lane_node_steps);
+    atomicAdd(&ctl->dbg[2], acc.wave_tri_steps); atomicAdd(&ctl->dbg[3], acc.lane_tri_steps);
+    atomicAdd(&ctl->dbg[4], acc.wave_outer);
+    if (ww.lane == 0) atomicAdd(&ctl->dbg[5], traced);
+#endif
     if (traced && ww.lane == 0) atomicAdd(gen == 0 ? &ctl->rays_primary : &ctl->rays_secondary, traced);
 }
 
 // InShadow, raytracer.cpp:1008-1244, one shadow slot per (record, point light).
-__global__ void __launch_bounds__(RT_TRACE_BLOCK) k_trace_shadow(DScene S, Pool P, Control* ctl, int gen, uint2* spill) {
-    __shared__ uint32_t s_link[(RT_TRACE_BLOCK / 64) * RT_STACK_LDS * 64];
-    __shared__ float s_t[(RT_TRACE_BLOCK / 64) * RT_STACK_LDS * 64];
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_shadow(DScene S, Pool P, Control* ctl, int gen, uint2* spill) {
+    __shared__ uint32_t s_link[(RT_TRACE_BLOCK / 64) * RT_LDS_ENTRIES * 64];
+    __shared__ float s_t[(RT_TRACE_BLOCK / 64) * RT_LDS_ENTRIES * 64];
     WaveWork ww;
     TraceStack st = make_stack(s_link, s_t, spill, ww);
     const uint32_t begin = ctl->sstart[gen], end = ctl->sstart[gen + 1];
+#ifdef RT_TRACE_STATS
+    TraceStatsAcc acc = {};   // the shadow kernel's counts are not reported, but traverse() writes through st.acc
+    st.acc = &acc;
+#endif
     unsigned long long traced = 0;
     for (;;) {
         uint32_t base = begin + ww.grab(&ctl->cursor_shadow);

@@ -289,7 +289,7 @@ def hip_lib():
     """librt_hip.so — the product.  Raises loudly when it is not built."""
     global _hip
     if _hip is None:
-        L = _load("librt_hip.so")
+        L = _load(os.environ.get("RT_HIP_SO", "librt_hip.so"))   # RT_HIP_SO: experiment builds (make variant)
         L.rt_device_count.restype = C.c_int
         L.rt_upload_scene.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.rt_scene_set_option.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
