@@ -53,6 +53,9 @@
 #ifndef RT_LEAF_QUEUE
 #define RT_LEAF_QUEUE 8          // mesh leaves a lane may postpone before the wave switches to triangle tests
 #endif
+#ifndef RT_LEAF_QUEUE_ANY
+#define RT_LEAF_QUEUE_ANY 4      // same for any-hit (shadow) rays: the first accepted hit ends the ray, so postpone less
+#endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4           // __launch_bounds__ waves per SIMD for the trace kernels
 #endif
@@ -270,6 +273,8 @@ __device__ bool traverse(const DScene& S, V3 ro, V3 rd, float time, float minT, 
     float mesh_beta = 0.f, mesh_gamma = 0.f;
     uint32_t cur_kind_index = 0;
     uint32_t qn = 0;             // postponed leaves in the queue
+    constexpr uint32_t QCAP = ANYHIT ? RT_LEAF_QUEUE_ANY : RT_LEAF_QUEUE;
+    static_assert(RT_LEAF_QUEUE_ANY <= RT_LEAF_QUEUE, "the LDS queue is sized by RT_LEAF_QUEUE");
 
     uint32_t cur = RT_LINK_DONE;
     float cur_t = 0.f;           // box entry distance of `cur`
@@ -289,7 +294,7 @@ __device__ bool traverse(const DScene& S, V3 ro, V3 rd, float time, float minT, 
             // leaf it still has queue room for.  The phase ends for the WAVE when no lane can
             // (wave-uniform exit: the two phases must not be interleaved by the compiler).
             const bool leaf_here = (cur & RT_LINK_LEAF) != 0;
-            const bool want = !leaf_here || (in_mesh && cur != RT_LINK_SENTINEL && qn < RT_LEAF_QUEUE);
+            const bool want = !leaf_here || (in_mesh && cur != RT_LINK_SENTINEL && qn < QCAP);
             if (!__any(want)) break;
             if (want) {
                 if (leaf_here) {
