@@ -93,10 +93,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # Rehearsal on a 1-GPU box: RT_BENCH_REHEARSE=1 puts every rank on GPU 0 and uses gloo (RCCL refuses two
+    # ranks on one device).  Never set by the driver; real runs are one rank per GPU over RCCL.
+    rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     W, H = frame_size(world)
     spec = scenes.mesh_scene(args.grid, W, H)
