@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -583,6 +584,9 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
                 d[0], d[1], d[0] ? d[1] / (64.0 * d[0]) : 0.0, d[2], d[3], d[2] ? d[3] / (64.0 * d[2]) : 0.0, d[4], d[5],
                 d[5] ? (double)d[1] / d[5] : 0.0, d[5] ? (double)d[3] / d[5] : 0.0, d[5] ? 64.0 * d[0] / d[5] : 0.0,
                 d[5] ? 64.0 * d[2] / d[5] : 0.0, d[5] ? 64.0 * d[4] / d[5] : 0.0);
+        // wall_clock64 ticks are 10 ns
+        fprintf(stderr, "[rt stats] closest timing: waves=%llu kernel span %.1f us, wave lifetime mean %.1f min %.1f max %.1f us\n",
+                d[13], (d[11] - ~d[10]) * 0.01, d[13] ? d[12] * 0.01 / d[13] : 0.0, (~d[15]) * 0.01, d[14] * 0.01);
     }
 #endif
     if (stats) {
@@ -644,11 +648,13 @@ int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out) {
     if (hipHostMalloc((void**)&sc->h_ctl, sizeof(Control)) != hipSuccess) { rt_free_scene(sc); return fail(RT_ERR_HIP, "hipHostMalloc failed"); }
     rc = build_device_scene(sc, scene);
     if (rc) { rt_free_scene(sc); return rc; }
-    int per_cu = 0;
+    // persistent grids: as many workgroups as are resident at once (RT_TRACE_BLOCKS_PER_CU caps it, for occupancy experiments)
+    int per_cu = 0, cap = 8;
+    if (const char* e = getenv("RT_TRACE_BLOCKS_PER_CU")) cap = std::max(1, std::min(8, atoi(e)));
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest, RT_TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-    sc->blocks_closest = sc->n_cu * std::min(per_cu, 8);
+    sc->blocks_closest = sc->n_cu * std::min(per_cu, cap);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_shadow, RT_TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-    sc->blocks_shadow = sc->n_cu * std::min(per_cu, 8);
+    sc->blocks_shadow = sc->n_cu * std::min(per_cu, cap);
     *out = sc;
     return RT_OK;
 }

@@ -282,12 +282,10 @@ struct WaveWork {
 
 // LDS per wave: RT_STACK_LDS stack entries + RT_LEAF_QUEUE postponed leaves, 8 bytes each per lane.
 #define RT_LDS_ENTRIES (RT_STACK_LDS + RT_LEAF_QUEUE)
-__device__ __forceinline__ TraceStack make_stack(uint32_t* s_link, float* s_t, uint2* spill, const WaveWork& ww) {
+__device__ __forceinline__ TraceStack make_stack(uint2* s_lds, uint2* spill, const WaveWork& ww) {
     TraceStack st;
-    st.lds_link = s_link + ww.wave * (RT_LDS_ENTRIES * 64);
-    st.lds_t = s_t + ww.wave * (RT_LDS_ENTRIES * 64);
-    st.q_link = st.lds_link + RT_STACK_LDS * 64;
-    st.q_t = st.lds_t + RT_STACK_LDS * 64;
+    st.lds = s_lds + ww.wave * (RT_LDS_ENTRIES * 64);
+    st.q = st.lds + RT_STACK_LDS * 64;
     size_t wave_slot = (size_t)blockIdx.x * (RT_TRACE_BLOCK / 64) + ww.wave;
     st.spill = spill + wave_slot * (size_t)((RT_STACK_MAX - RT_STACK_LDS) * 64);
     st.lane = ww.lane;
@@ -300,83 +298,74 @@ __device__ __forceinline__ TraceStack make_stack(uint32_t* s_link, float* s_t, u
 }
 
 // FindClosestHit's search part (raytracer.cpp:405-444) for generation `gen`.
-__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_closest(DScene S, Pool P, Control* ctl, int gen, uint2* spill) {
-    __shared__ uint32_t s_link[(RT_TRACE_BLOCK / 64) * RT_LDS_ENTRIES * 64];
-    __shared__ float s_t[(RT_TRACE_BLOCK / 64) * RT_LDS_ENTRIES * 64];
-    WaveWork ww;
-    TraceStack st = make_stack(s_link, s_t, spill, ww);
-    const uint32_t begin = ctl->gstart[gen], end = ctl->gstart[gen + 1];
-#ifdef RT_TRACE_STATS
-    TraceStatsAcc acc = {};
-    st.acc = &acc;
-#endif
-    unsigned long long traced = 0;   // wave-uniform
-    for (;;) {
-        // every lane of the wave reaches this point together: the body below is
-        // one structured `if`, and the exit test is wave-uniform
-        uint32_t base = begin + ww.grab(&ctl->cursor_closest);
-        if (base >= end) break;
-        const uint32_t r = base + ww.lane;
-        const bool in_range = r < end;
-        float4 r0 = make_float4(0, 0, 0, 0), r1 = make_float4(0, 0, 0, 0);
-        if (in_range) { r0 = P.ray0[r]; r1 = P.ray1[r]; }
-        HitOut h;
-        h.t = RT_FLT_MAX;
+struct ClosestIO {
+    const DScene& S;
+    const Pool& P;
+    __device__ __forceinline__ int load(uint32_t r, V3& o, V3& d, float& time, float& minT, bool& has, HitOut& h) const {
+        const float4 r0 = P.ray0[r], r1 = P.ray1[r];
         h.kind_index = 0xFFFFFFFFu;
         h.tri = 0;
         h.beta = 0.f;
         h.gamma = 0.f;
-        const bool live = in_range && __float_as_uint(r1.w) != 0u;
-        traced += __popcll(__ballot(live));
-        if (live) {
-            V3 o = mk(r0.x, r0.y, r0.z), d = mk(r1.x, r1.y, r1.z);
-            float minT = RT_FLT_MAX;
-            bool has = false;
-            for (uint32_t i = 0; i < S.n_planes; i++) {   // raytracer.cpp:423-435
-                float t;
-                if (plane_test(o, d, S.planes[i], minT, t)) {
-                    minT = t;
-                    has = true;
-                    h.kind_index = (RT_KIND_PLANE << 28) | i;
-                }
+        if (__float_as_uint(r1.w) == 0u) {   // padding record of an edge tile
+            P.hit0[r] = make_uint4(__float_as_uint(RT_FLT_MAX), 0xFFFFFFFFu, 0u, 0u);
+            P.hit1[r] = make_float2(0.f, 0.f);
+            return 0;
+        }
+        o = mk(r0.x, r0.y, r0.z);
+        d = mk(r1.x, r1.y, r1.z);
+        time = r0.w;
+        minT = RT_FLT_MAX;
+        has = false;
+        for (uint32_t i = 0; i < S.n_planes; i++) {   // raytracer.cpp:423-435
+            float t;
+            if (plane_test(o, d, S.planes[i], minT, t)) {
+                minT = t;
+                has = true;
+                h.kind_index = (RT_KIND_PLANE << 28) | i;
             }
-            has = traverse<false>(S, o, d, r0.w, minT, has, h, st);
-            if (!has) h.kind_index = 0xFFFFFFFFu;
         }
-        if (in_range) {
-            P.hit0[r] = make_uint4(__float_as_uint(h.t), h.kind_index, h.tri, 0u);
-            P.hit1[r] = make_float2(h.beta, h.gamma);
-        }
+        return 2;
     }
+    __device__ __forceinline__ void store(uint32_t r, bool has, const HitOut& h, float minT) const {
+        P.hit0[r] = make_uint4(__float_as_uint(minT), has ? h.kind_index : 0xFFFFFFFFu, h.tri, 0u);
+        P.hit1[r] = make_float2(h.beta, h.gamma);
+    }
+};
+
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_closest(DScene S, Pool P, Control* ctl, int gen, uint2* spill) {
+    __shared__ uint2 s_lds[(RT_TRACE_BLOCK / 64) * RT_LDS_ENTRIES * 64];
+    WaveWork ww;
+    TraceStack st = make_stack(s_lds, spill, ww);
+    const uint32_t begin = ctl->gstart[gen], end = ctl->gstart[gen + 1];
+#ifdef RT_TRACE_STATS
+    TraceStatsAcc acc = {};
+    st.acc = &acc;
+    const unsigned long long clk_start = wall_clock64();
+#endif
+    unsigned long long traced = 0;   // wave-uniform
+    ClosestIO io{S, P};
+    trace_persistent<false>(S, io, begin, end, &ctl->cursor_closest, st, traced);
     if (st.overflow) atomicOr(&ctl->overflow, 4u);
 #ifdef RT_TRACE_STATS
     atomicAdd(&ctl->dbg[0], acc.wave_node_steps); atomicAdd(&ctl->dbg[1], acc.lane_node_steps);
     atomicAdd(&ctl->dbg[2], acc.wave_tri_steps); atomicAdd(&ctl->dbg[3], acc.lane_tri_steps);
     atomicAdd(&ctl->dbg[4], acc.wave_outer);
-    if (ww.lane == 0) atomicAdd(&ctl->dbg[5], traced);
+    if (ww.lane == 0) {
+        atomicAdd(&ctl->dbg[5], traced);
+        const unsigned long long clk_end = wall_clock64();
+        atomicMax(&ctl->dbg[10], ~clk_start); atomicMax(&ctl->dbg[11], clk_end); atomicAdd(&ctl->dbg[12], clk_end - clk_start); atomicAdd(&ctl->dbg[13], 1ull);
+        atomicMax(&ctl->dbg[14], clk_end - clk_start); atomicMax(&ctl->dbg[15], ~(clk_end - clk_start));
+    }
 #endif
     if (traced && ww.lane == 0) atomicAdd(gen == 0 ? &ctl->rays_primary : &ctl->rays_secondary, traced);
 }
 
 // InShadow, raytracer.cpp:1008-1244, one shadow slot per (record, point light).
-__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_shadow(DScene S, Pool P, Control* ctl, int gen, uint2* spill) {
-    __shared__ uint32_t s_link[(RT_TRACE_BLOCK / 64) * RT_LDS_ENTRIES * 64];
-    __shared__ float s_t[(RT_TRACE_BLOCK / 64) * RT_LDS_ENTRIES * 64];
-    WaveWork ww;
-    TraceStack st = make_stack(s_link, s_t, spill, ww);
-    const uint32_t begin = ctl->sstart[gen], end = ctl->sstart[gen + 1];
-#ifdef RT_TRACE_STATS
-    TraceStatsAcc acc = {};   // the shadow kernel's counts are not reported, but traverse() writes through st.acc
-    st.acc = &acc;
-#endif
-    unsigned long long traced = 0;
-    for (;;) {
-        uint32_t base = begin + ww.grab(&ctl->cursor_shadow);
-        if (base >= end) break;
-        const uint32_t i = base + ww.lane;
-        const bool in_range = i < end;
-        traced += __popcll(__ballot(in_range));
-        if (in_range) {
+struct ShadowIO {
+    const DScene& S;
+    const Pool& P;
+    __device__ __forceinline__ int load(uint32_t i, V3& so, V3& sd, float& time, float& minT, bool& has, HitOut& h) const {
         const uint32_t r = P.shadow_rec[i];
         const uint32_t light = i - P.link[r].z;
         const float4 r0 = P.ray0[r], r1 = P.ray1[r], nn = P.nrm[r];
@@ -388,21 +377,32 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_shadow(D
         const DPointLight L = S.point_lights[light];
         V3 toLight = mk(L.px, L.py, L.pz) - x;
         float dist = vlen(toLight);
-        V3 so = x + n_shading * S.shadow_eps;
-        V3 sd = vdiv(toLight, dist);
-        float minT = dist;
-        bool shadow = false;
-        for (uint32_t k = 0; k < S.n_planes && !shadow; k++) {
+        so = x + n_shading * S.shadow_eps;
+        sd = vdiv(toLight, dist);
+        time = r0.w;
+        minT = dist;
+        has = false;
+        for (uint32_t k = 0; k < S.n_planes; k++) {            // raytracer.cpp:1022-1028
             float t;
-            if (plane_test(so, sd, S.planes[k], minT, t)) shadow = true;
+            if (plane_test(so, sd, S.planes[k], minT, t)) { P.shadow_lit[i] = 0; return 1; }
         }
-        if (!shadow) {
-            HitOut h;
-            shadow = traverse<true>(S, so, sd, r0.w, minT, false, h, st);
-        }
-        P.shadow_lit[i] = shadow ? 0 : 1;
-        }
+        return 2;
     }
+    __device__ __forceinline__ void store(uint32_t i, bool shadow, const HitOut&, float) const { P.shadow_lit[i] = shadow ? 0 : 1; }
+};
+
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_shadow(DScene S, Pool P, Control* ctl, int gen, uint2* spill) {
+    __shared__ uint2 s_lds[(RT_TRACE_BLOCK / 64) * RT_LDS_ENTRIES * 64];
+    WaveWork ww;
+    TraceStack st = make_stack(s_lds, spill, ww);
+    const uint32_t begin = ctl->sstart[gen], end = ctl->sstart[gen + 1];
+#ifdef RT_TRACE_STATS
+    TraceStatsAcc acc = {};   // the shadow kernel's counts are not reported, but the loop writes through st.acc
+    st.acc = &acc;
+#endif
+    unsigned long long traced = 0;
+    ShadowIO io{S, P};
+    trace_persistent<true>(S, io, begin, end, &ctl->cursor_shadow, st, traced);
     if (st.overflow) atomicOr(&ctl->overflow, 4u);
     if (traced && ww.lane == 0) atomicAdd(&ctl->rays_shadow, traced);
 }

@@ -59,6 +59,12 @@
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4           // __launch_bounds__ waves per SIMD for the trace kernels
 #endif
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 16         // idle lanes of a wave that trigger a refill from the generation's cursor
+#endif
+#ifndef RT_COOP_MIN
+#define RT_COOP_MIN 64           // a leaf with at least this many triangles is tested by the whole wave for one ray
+#endif
 #define RT_STACK_MAX 64          // the reference's stack[64] (raytracer.cpp:533,766)
 #define RT_TRACE_BLOCK 256       // 4 waves per workgroup
 
@@ -73,12 +79,13 @@ struct TraceStatsAcc {
 #define RT_STAT(x)
 #endif
 
+typedef float f4a __attribute__((ext_vector_type(4)));
+typedef f4a f4u __attribute__((aligned(4)));   // 4 floats at dword alignment: one global_load_dwordx4
+
 struct TraceStack {
-    uint32_t* lds_link;   // [RT_STACK_LDS][64] for this wave
-    float*    lds_t;      // [RT_STACK_LDS][64]
+    uint2*    lds;        // [RT_STACK_LDS][64] for this wave: (link, bits of tEnter)
     uint2*    spill;      // [(RT_STACK_MAX-RT_STACK_LDS)][64] for this wave (global)
-    uint32_t* q_link;     // [RT_LEAF_QUEUE][64] postponed mesh leaves, in visiting order
-    float*    q_t;        // [RT_LEAF_QUEUE][64] their box entry distances
+    uint2*    q;          // [RT_LEAF_QUEUE][64] postponed mesh leaves, in visiting order: (link, bits of tEnter)
     uint32_t  lane;
     uint32_t  sp;
     uint32_t  overflow;
@@ -88,8 +95,7 @@ struct TraceStack {
 
     __device__ __forceinline__ void push(uint32_t link, float t) {
         if (sp < RT_STACK_LDS) {
-            lds_link[sp * 64 + lane] = link;
-            lds_t[sp * 64 + lane] = t;
+            lds[sp * 64 + lane] = make_uint2(link, __float_as_uint(t));
         } else if (sp < RT_STACK_MAX) {
             spill[(sp - RT_STACK_LDS) * 64 + lane] = make_uint2(link, __float_as_uint(t));
         } else {
@@ -98,21 +104,24 @@ struct TraceStack {
         }
         sp++;
     }
+    // push when the caller has established (wave-wide) that the entry lands in the LDS part
+    __device__ __forceinline__ void push_lds(uint32_t link, float t) {
+        lds[sp * 64 + lane] = make_uint2(link, __float_as_uint(t));
+        sp++;
+    }
     // Pop the next entry the reference would not cull (see file header).
     __device__ __forceinline__ uint32_t pop(float tmax, float& t_out) {
         while (sp > 0) {
             --sp;
-            uint32_t link;
-            float t;
+            uint2 e;
             if (sp < RT_STACK_LDS) {
-                link = lds_link[sp * 64 + lane];
-                t = lds_t[sp * 64 + lane];
+                e = lds[sp * 64 + lane];
             } else {
-                uint2 e = spill[(sp - RT_STACK_LDS) * 64 + lane];
-                link = e.x;
-                t = __uint_as_float(e.y);
+                e = spill[(sp - RT_STACK_LDS) * 64 + lane];
+                asm volatile("" : "+v"(e.x));   // keep the rare global path a branch (else both merge into one flat load)
             }
-            if (!((tmax < t) || (t == 0.0f && tmax <= 0.0f))) { t_out = t; return link; }
+            const float t = __uint_as_float(e.y);
+            if (!((tmax < t) || (t == 0.0f && tmax <= 0.0f))) { t_out = t; return e.x; }
         }
         return RT_LINK_DONE;
     }
@@ -154,22 +163,24 @@ __device__ __forceinline__ bool box_test(const ActiveRay& r, float mnx, float mn
 }
 
 // IntersectsTriangle_Bary, raytracer.cpp:896-947, with col_A0/col_A1 preloaded.
+// Straight-line form: the reference's early returns become one verdict (each
+// condition is evaluated on the same values in the same order; a quotient by a
+// detA that failed the first test is computed but never looked at), so a wave
+// whose lanes test different triangles executes no divergent branches.
 __device__ __forceinline__ bool tri_test(const ActiveRay& r, float ax, float ay, float az, float e1x, float e1y,
                                          float e1z, float e2x, float e2y, float e2z, float minT, float& t_out,
                                          float& beta_out, float& gamma_out) {
-    float bx = ax - r.ox, by = ay - r.oy, bz = az - r.oz;
-    float detA = det3x3(e1x, e2x, r.dx, e1y, e2y, r.dy, e1z, e2z, r.dz);
-    if (fabsf(detA) < RT_EPS_PARALLEL) return false;
-    float beta = det3x3(bx, e2x, r.dx, by, e2y, r.dy, bz, e2z, r.dz) / detA;
-    if (beta < -RT_EPS_PARALLEL) return false;
-    float gamma = det3x3(e1x, bx, r.dx, e1y, by, r.dy, e1z, bz, r.dz) / detA;
-    if ((gamma < -RT_EPS_PARALLEL) || ((beta + gamma) > (1.0f + RT_EPS_PARALLEL))) return false;
-    float t = det3x3(e1x, e2x, bx, e1y, e2y, by, e1z, e2z, bz) / detA;
-    if (t < -RT_EPS_PARALLEL || t >= minT) return false;
+    const float bx = ax - r.ox, by = ay - r.oy, bz = az - r.oz;
+    const float detA = det3x3(e1x, e2x, r.dx, e1y, e2y, r.dy, e1z, e2z, r.dz);
+    const float beta = det3x3(bx, e2x, r.dx, by, e2y, r.dy, bz, e2z, r.dz) / detA;
+    const float gamma = det3x3(e1x, bx, r.dx, e1y, by, r.dy, e1z, bz, r.dz) / detA;
+    const float t = det3x3(e1x, e2x, bx, e1y, e2y, by, e1z, e2z, bz) / detA;
+    const bool rej = (fabsf(detA) < RT_EPS_PARALLEL) | (beta < -RT_EPS_PARALLEL) | (gamma < -RT_EPS_PARALLEL) |
+                     ((beta + gamma) > (1.0f + RT_EPS_PARALLEL)) | (t < -RT_EPS_PARALLEL) | (t >= minT);
     t_out = t;
     beta_out = beta;
     gamma_out = gamma;
-    return true;
+    return !rej;
 }
 
 // IntersectSphere, raytracer.cpp:949-980 (sqrt(double(delta)) narrowed to float
@@ -253,53 +264,116 @@ __device__ __forceinline__ uint32_t leaf_count(const DScene& S, uint32_t link, b
     return S.big_leaves[lo].count;
 }
 
-// Traverse the scene's BVHs.  On entry `minT`/`has`/`out` carry the result of
-// the plane loop (FindClosestHit raytracer.cpp:423-435 / InShadow :1022-1028).
-// ANYHIT: returns true at the first accepted hit (InShadow).  Otherwise updates
-// out/minT and returns `has`.
-template <bool ANYHIT>
-__device__ bool traverse(const DScene& S, V3 ro, V3 rd, float time, float minT, bool has, HitOut& out,
-                         TraceStack& st) {
-    st.sp = 0;
+// Is `link` a mesh leaf whose primitive count is in the side table (>= RT_LEAF_BIG prims)?
+// Leaf bit + count code 31 = the top six bits; the three special links share them.
+__device__ __forceinline__ bool is_big_leaf_link(uint32_t link) { return link >= 0xFC000000u && link < RT_LINK_NONE; }
+
+__device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+
+// The persistent trace loop of one wave: FindClosestHit's BVH part (ANYHIT = false)
+// or InShadow's (ANYHIT = true) for the items [begin, end) of a generation.
+//
+// Scheduling: the 64 lanes are 64 ray slots.  A lane whose
+// ray is finished stores its result and goes idle; when RT_REFILL_MIN lanes are
+// idle the wave takes that many consecutive items from the generation's cursor
+// (one atomic) and hands them to the idle lanes.  So a wave is not bound to the
+// slowest ray of a fixed 64-ray batch (on the 1M-triangle frame the slowest batch
+// took 2.3 ms, three times the mean lifetime of a wave), while refilling in runs
+// keeps neighbouring pixels together.
+//
+// IO::load(item, o, d, time, minT, has, out) -> int  sets up the ray (plane loop
+//   included, raytracer.cpp:423-435 / :1022-1028) and returns 2, or stores a final
+//   result itself and returns 1 (a ray that needs no traversal) or 0 (no ray);
+//   IO::store(item, verdict, out, minT) stores the result of a traversed ray
+//   (verdict = has / in-shadow).
+template <bool ANYHIT, class IO>
+__device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32_t end, uint32_t* cursor, TraceStack& st,
+                                 unsigned long long& traced) {
+    constexpr uint32_t QCAP = ANYHIT ? RT_LEAF_QUEUE_ANY : RT_LEAF_QUEUE;
+    static_assert(RT_LEAF_QUEUE_ANY <= RT_LEAF_QUEUE, "the LDS queue is sized by RT_LEAF_QUEUE");
+    const uint32_t lane = st.lane;
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
+
+    // ---- per-lane ray slot
+    bool alive = false;
+    uint32_t item = 0;
+    V3 ro = mk(0, 0, 0), rd = mk(0, 0, 0);
+    float time = 0.f, minT = 0.f;
+    bool has = false;
+    HitOut out;
+    out.t = 0.f; out.kind_index = 0xFFFFFFFFu; out.tri = 0; out.beta = 0.f; out.gamma = 0.f;
     ActiveRay ar;
     ar.set(ro, rd);
-    float tmax = minT;           // culling bound of the active level
+    float tmax = 0.f;            // culling bound of the active level
     bool in_mesh = false;
     uint32_t top_slot = 0, top_remaining = 0;
-    // state of the mesh traversal in flight
-    uint32_t cur_obj = 0;
+    uint32_t cur_obj = 0;        // state of the mesh traversal in flight
     bool mesh_found = false;
     uint32_t mesh_tri = 0;
     float mesh_beta = 0.f, mesh_gamma = 0.f;
     uint32_t cur_kind_index = 0;
     uint32_t qn = 0;             // postponed leaves in the queue
-    constexpr uint32_t QCAP = ANYHIT ? RT_LEAF_QUEUE_ANY : RT_LEAF_QUEUE;
-    static_assert(RT_LEAF_QUEUE_ANY <= RT_LEAF_QUEUE, "the LDS queue is sized by RT_LEAF_QUEUE");
-
     uint32_t cur = RT_LINK_DONE;
     float cur_t = 0.f;           // box entry distance of `cur`
-    if (S.top_root_link != RT_LINK_DONE) {
-        float te;
-        if (box_test(ar, S.top_rmin[0], S.top_rmin[1], S.top_rmin[2], S.top_rmax[0], S.top_rmax[1], S.top_rmax[2], tmax, te)) {
-            cur = S.top_root_link;
-            cur_t = te;
-        }
-    }
+    bool exhausted = false;      // wave-uniform: the cursor has passed `end`
+    st.sp = 0;
 
     for (;;) {
+        // ---- refill idle lanes (wave-uniform control flow)
+        if (!exhausted) {
+            const uint64_t idle = __ballot(!alive);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (n_idle >= RT_REFILL_MIN) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(cursor, n_idle);
+                base = begin + (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base + n_idle >= end) exhausted = true;
+                int got = 0;
+                if (!alive) {
+                    const uint32_t i = base + (uint32_t)__popcll(idle & lanes_below);
+                    if (i < end) {
+                        item = i;
+                        got = io.load(i, ro, rd, time, minT, has, out);
+                    }
+                }
+                traced += __popcll(__ballot(got != 0));
+                if (got == 2) {
+                    alive = true;
+                    st.sp = 0;
+                    in_mesh = false;
+                    qn = 0;
+                    ar.set(ro, rd);
+                    tmax = minT;
+                    cur = RT_LINK_DONE;
+                    if (S.top_root_link != RT_LINK_DONE) {
+                        float te;
+                        if (box_test(ar, S.top_rmin[0], S.top_rmin[1], S.top_rmin[2], S.top_rmax[0], S.top_rmax[1], S.top_rmax[2], tmax, te)) {
+                            cur = S.top_root_link;
+                            cur_t = te;
+                        }
+                    }
+                }
+            }
+        }
+        if (!__any(alive)) {
+            if (exhausted) break;
+            continue;
+        }
+
         // ---- node phase: collapsed interior records of either level; mesh leaves are queued
         RT_STAT(if (st.lane == __ffsll((long long)__ballot(1)) - 1) st.acc->wave_outer++;)
         for (;;) {
             // A lane can make progress here while it sits on an interior record, or on a mesh
-            // leaf it still has queue room for.  The phase ends for the WAVE when no lane can
+            // leaf it still has queue room for (big leaves wait for the triangle phase; idle
+            // lanes sit on RT_LINK_DONE).  The phase ends for the WAVE when no lane can
             // (wave-uniform exit: the two phases must not be interleaved by the compiler).
             const bool leaf_here = (cur & RT_LINK_LEAF) != 0;
-            const bool want = !leaf_here || (in_mesh && cur != RT_LINK_SENTINEL && qn < QCAP);
+            const bool want = !leaf_here || (in_mesh && cur < 0xFC000000u && qn < QCAP);
             if (!__any(want)) break;
             if (want) {
                 if (leaf_here) {
-                    st.q_link[qn * 64 + st.lane] = cur;
-                    st.q_t[qn * 64 + st.lane] = cur_t;
+                    st.q[qn * 64 + st.lane] = make_uint2(cur, __float_as_uint(cur_t));
                     qn++;
                     cur = st.pop(tmax, cur_t);
                 }
@@ -308,37 +382,50 @@ __device__ bool traverse(const DScene& S, V3 ro, V3 rd, float time, float minT, 
                     const float4* p = reinterpret_cast<const float4*>(&S.nodes[cur]);
                     const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
                     const uint4 lk = reinterpret_cast<const uint4*>(p)[6];
-                    const uint32_t mask = reinterpret_cast<const uint32_t*>(p)[28];
                     float t0, t1, t2, t3;
-                    const bool h0 = box_test(ar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax, t0);                 // slot 0 is always valid
-                    const bool h1 = box_test(ar, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax, t1) && (mask & 2u);
-                    const bool h2 = box_test(ar, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, tmax, t2) && (mask & 4u);
-                    const bool h3 = box_test(ar, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, tmax, t3) && (mask & 8u);
-                    // visit order = slot order; later hits are pushed last-first so they pop in order
-                    uint32_t nx = RT_LINK_NONE;
-                    float tn = 0.f;
-                    if (h3) { nx = lk.w; tn = t3; }
-                    if (h2) { if (nx != RT_LINK_NONE) st.push(nx, tn); nx = lk.z; tn = t2; }
-                    if (h1) { if (nx != RT_LINK_NONE) st.push(nx, tn); nx = lk.y; tn = t1; }
-                    if (h0) { if (nx != RT_LINK_NONE) st.push(nx, tn); nx = lk.x; tn = t0; }
-                    if (nx != RT_LINK_NONE) { cur = nx; cur_t = tn; }
+                    // slot 0 is always valid; an empty slot carries RT_LINK_DONE
+                    const bool h0 = box_test(ar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax, t0);
+                    const bool h1 = box_test(ar, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax, t1) & (lk.y != RT_LINK_DONE);
+                    const bool h2 = box_test(ar, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, tmax, t2) & (lk.z != RT_LINK_DONE);
+                    const bool h3 = box_test(ar, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, tmax, t3) & (lk.w != RT_LINK_DONE);
+                    // visit order = slot order: the first hit slot is next, the later ones are
+                    // pushed last-first so that they pop in order
+                    const bool p1 = h1 & h0, p2 = h2 & (h0 | h1), p3 = h3 & (h0 | h1 | h2);
+                    if (!__any(st.sp + 3 > RT_STACK_LDS)) {
+                        if (p3) st.push_lds(lk.w, t3);
+                        if (p2) st.push_lds(lk.z, t2);
+                        if (p1) st.push_lds(lk.y, t1);
+                    } else {
+                        if (p3) st.push(lk.w, t3);
+                        if (p2) st.push(lk.z, t2);
+                        if (p1) st.push(lk.y, t1);
+                    }
+                    if (h0) { cur = lk.x; cur_t = t0; }
+                    else if (h1) { cur = lk.y; cur_t = t1; }
+                    else if (h2) { cur = lk.z; cur_t = t2; }
+                    else if (h3) { cur = lk.w; cur_t = t3; }
                     else cur = st.pop(tmax, cur_t);
                 }
             }
         }
 
         // ---- triangle phase: the postponed leaves, in visiting order (raytracer.cpp:781-798)
-        for (uint32_t qi = 0; qi < qn; qi++) {
-            const uint32_t link = st.q_link[qi * 64 + st.lane];
-            const float te = st.q_t[qi * 64 + st.lane];
+        bool fin = false;        // this lane's ray is finished (ANYHIT: with verdict "in shadow")
+        for (uint32_t qi = 0; qi < qn && !fin; qi++) {
+            const uint2 qe = st.q[qi * 64 + st.lane];
+            const uint32_t link = qe.x;
+            const float te = __uint_as_float(qe.y);
             if ((tmax < te) || (te == 0.0f && tmax <= 0.0f)) continue;   // the reference would cull this leaf's box now
             uint32_t ti = RT_LEAF_FIRST(link);
-            uint32_t n = leaf_count(S, link, false);
+            uint32_t n = RT_LEAF_COUNT(link);                            // < RT_LEAF_BIG: big leaves are never queued
             for (; n != 0; n--, ti++) {
                 RT_STAT({ unsigned long long m = __ballot(1); if (st.lane == __ffsll((long long)m) - 1) { st.acc->wave_tri_steps++; st.acc->lane_tri_steps += __popcll(m); } })
+                // 36-byte record as dwordx4 + dwordx4 + dword, all issued before the test
                 const float* tp = reinterpret_cast<const float*>(&S.tris[ti]);
+                const f4u ta = *reinterpret_cast<const f4u*>(tp), tb = *reinterpret_cast<const f4u*>(tp + 4);
+                const float tc = tp[8];
                 float t, bb, gg;
-                if (tri_test(ar, tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6], tp[7], tp[8], tmax, t, bb, gg)) {
+                if (tri_test(ar, ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w, tc, tmax, t, bb, gg)) {
                     tmax = t;
                     mesh_found = true;
                     mesh_tri = ti;
@@ -347,104 +434,193 @@ __device__ bool traverse(const DScene& S, V3 ro, V3 rd, float time, float minT, 
                     if (ANYHIT) {
                         // Untransformed mesh: worldT == t < testMinT == minT, so the
                         // reference's verdict is already known.
-                        if (!(S.objects[cur_obj].flags & RT_OBJ_HAS_TRANSFORM)) return true;
+                        if (!(S.objects[cur_obj].flags & RT_OBJ_HAS_TRANSFORM)) { fin = true; break; }
                     }
                 }
             }
         }
         qn = 0;
 
-        if (in_mesh) {
-            if (cur != RT_LINK_SENTINEL) {
-                // a mesh leaf is waiting (queue was full): it was accepted with an older minT, re-check it
-                if ((tmax < cur_t) || (cur_t == 0.0f && tmax <= 0.0f)) cur = st.pop(tmax, cur_t);
-                continue;
-            }
-            // ---- mesh traversal finished (IntersectMeshBVH returned), raytracer.cpp:596-620
-            in_mesh = false;
-            if (mesh_found) {
-                const DObject& ob = S.objects[cur_obj];
-                float wt = world_t(ob, ro, time, mk(ar.ox, ar.oy, ar.oz), mk(ar.dx, ar.dy, ar.dz), tmax);
-                if (wt < minT) {
-                    if (ANYHIT) return true;
-                    minT = wt;
-                    has = true;
-                    out.kind_index = cur_kind_index;
-                    out.tri = mesh_tri;
-                    out.beta = mesh_beta;
-                    out.gamma = mesh_gamma;
+        // ---- a big leaf (>= RT_LEAF_BIG triangles, raytracer.cpp:183: an unsplittable node) waiting at `cur`.
+        // It follows the queued leaves in visiting order.  Below RT_COOP_MIN triangles the lane tests it
+        // alone; from RT_COOP_MIN on the whole wave tests it for that lane, 64 triangles per step: the
+        // sequential scan `if (t < minT) minT = t` ends at the first triangle that attains the smallest
+        // t below the incoming bound, which is what the (t, index) minimum over the lanes selects.
+        bool big = alive && !fin && in_mesh && is_big_leaf_link(cur);
+        if (big && ((tmax < cur_t) || (cur_t == 0.0f && tmax <= 0.0f))) { big = false; cur = st.pop(tmax, cur_t); }
+        if (__any(big)) {
+            uint32_t big_first = 0, big_n = 0;
+            if (big) {
+                big_first = RT_LEAF_FIRST(cur);
+                big_n = leaf_count(S, cur, false);
+                if (big_n < RT_COOP_MIN) {
+                    uint32_t ti = big_first;
+                    for (uint32_t n = big_n; n != 0; n--, ti++) {
+                        const float* tp = reinterpret_cast<const float*>(&S.tris[ti]);
+                        const f4u ta = *reinterpret_cast<const f4u*>(tp), tb = *reinterpret_cast<const f4u*>(tp + 4);
+                        const float tc = tp[8];
+                        float t, bb, gg;
+                        if (tri_test(ar, ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w, tc, tmax, t, bb, gg)) {
+                            tmax = t;
+                            mesh_found = true;
+                            mesh_tri = ti;
+                            mesh_beta = bb;
+                            mesh_gamma = gg;
+                            if (ANYHIT) {
+                                if (!(S.objects[cur_obj].flags & RT_OBJ_HAS_TRANSFORM)) { fin = true; break; }
+                            }
+                        }
+                    }
                 }
             }
-            ar.set(ro, rd);
-            tmax = minT;
-        } else {
-            if (cur == RT_LINK_DONE) break;
-            top_slot = RT_LEAF_FIRST(cur);
-            top_remaining = leaf_count(S, cur, true);
+            uint64_t coop = __ballot(big && big_n >= RT_COOP_MIN);
+            while (coop != 0) {                      // wave-uniform; every lane (idle ones too) takes part
+                const int src = __ffsll((long long)coop) - 1;
+                coop &= coop - 1;
+                ActiveRay br;
+                br.ox = lane_bcast(ar.ox, src); br.oy = lane_bcast(ar.oy, src); br.oz = lane_bcast(ar.oz, src);
+                br.dx = lane_bcast(ar.dx, src); br.dy = lane_bcast(ar.dy, src); br.dz = lane_bcast(ar.dz, src);
+                br.ix = br.iy = br.iz = 0.f;         // not used by tri_test
+                const float bound = lane_bcast(tmax, src);
+                const uint32_t first = lane_bcast(big_first, src), count = lane_bcast(big_n, src);
+                float best_t = bound, best_b = 0.f, best_g = 0.f;
+                uint32_t best_i = 0xFFFFFFFFu;
+                for (uint32_t k = lane; k < count; k += 64) {
+                    const float* tp = reinterpret_cast<const float*>(&S.tris[first + k]);
+                    const f4u ta = *reinterpret_cast<const f4u*>(tp), tb = *reinterpret_cast<const f4u*>(tp + 4);
+                    const float tc = tp[8];
+                    float t, bb, gg;
+                    if (tri_test(br, ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w, tc, bound, t, bb, gg) && t < best_t) {
+                        best_t = t; best_i = first + k; best_b = bb; best_g = gg;
+                    }
+                }
+                float red_t = best_t;
+                uint32_t red_i = best_i;
+                for (int off = 32; off != 0; off >>= 1) {
+                    const float ot = __shfl_xor(red_t, off);
+                    const uint32_t oi = (uint32_t)__shfl_xor((int)red_i, off);
+                    if (ot < red_t || (ot == red_t && oi < red_i)) { red_t = ot; red_i = oi; }
+                }
+                if (red_i != 0xFFFFFFFFu) {          // wave-uniform after the butterfly
+                    const int win = __ffsll((long long)__ballot(best_i == red_i)) - 1;
+                    const float wb = lane_bcast(best_b, win), wg = lane_bcast(best_g, win);
+                    if ((int)lane == src) {
+                        tmax = red_t;
+                        mesh_found = true;
+                        mesh_tri = red_i;
+                        mesh_beta = wb;
+                        mesh_gamma = wg;
+                        if (ANYHIT) {
+                            if (!(S.objects[cur_obj].flags & RT_OBJ_HAS_TRANSFORM)) fin = true;
+                        }
+                    }
+                }
+            }
+            if (big && !fin) cur = st.pop(tmax, cur_t);
         }
 
-        // ---- prims of the current top-level leaf, in order (raytracer.cpp:548-745)
-        bool entered = false;
-        while (top_remaining != 0) {
-            const DTopPrim tp = S.top_prims[top_slot];
-            top_slot++;
-            top_remaining--;
-            const DObject& ob = S.objects[tp.obj];
-            V3 to, td;
-            float testMinT;
-            object_space_ray(ob, ro, rd, time, minT, to, td, testMinT);
-            if (tp.kind == RT_KIND_MESH) {
-                if (ob.root_link == RT_LINK_DONE) continue;
-                ActiveRay mr;
-                mr.set(to, td);
-                float te;
-                if (!box_test(mr, ob.rminx, ob.rminy, ob.rminz, ob.rmaxx, ob.rmaxy, ob.rmaxz, testMinT, te)) continue;
-                ar = mr;
-                tmax = testMinT;
-                cur_obj = tp.obj;
-                cur_kind_index = (RT_KIND_MESH << 28) | tp.index;
-                mesh_found = false;
-                in_mesh = true;
-                st.push(RT_LINK_SENTINEL, -1.0f);
-                cur = ob.root_link;
-                cur_t = te;
-                entered = true;
-                break;
-            } else if (tp.kind == RT_KIND_SPHERE) {
-                ActiveRay sr;
-                sr.set(to, td);
-                float t;
-                if (sphere_test(sr, ob.p[0], ob.p[1], ob.p[2], ob.p[3], testMinT, t)) {
-                    float wt = world_t(ob, ro, time, to, td, t);
+        // ---- per-lane transitions between the levels
+        bool finished = fin;
+        if (alive && !fin) do {
+            if (in_mesh) {
+                if (cur != RT_LINK_SENTINEL) {
+                    // a mesh leaf is waiting (queue was full): it was accepted with an older minT, re-check it
+                    if ((cur & RT_LINK_LEAF) && ((tmax < cur_t) || (cur_t == 0.0f && tmax <= 0.0f))) cur = st.pop(tmax, cur_t);
+                    break;
+                }
+                // ---- mesh traversal finished (IntersectMeshBVH returned), raytracer.cpp:596-620
+                in_mesh = false;
+                if (mesh_found) {
+                    const DObject& ob = S.objects[cur_obj];
+                    float wt = world_t(ob, ro, time, mk(ar.ox, ar.oy, ar.oz), mk(ar.dx, ar.dy, ar.dz), tmax);
                     if (wt < minT) {
-                        if (ANYHIT) return true;
+                        if (ANYHIT) { fin = true; finished = true; break; }
                         minT = wt;
                         has = true;
-                        out.kind_index = (RT_KIND_SPHERE << 28) | tp.index;
-                        out.tri = 0;
-                        tmax = minT;
+                        out.kind_index = cur_kind_index;
+                        out.tri = mesh_tri;
+                        out.beta = mesh_beta;
+                        out.gamma = mesh_gamma;
                     }
                 }
-            } else {   // RT_KIND_TRIANGLE
-                ActiveRay tr;
-                tr.set(to, td);
-                float t, bb, gg;
-                if (tri_test(tr, ob.p[0], ob.p[1], ob.p[2], ob.p[3], ob.p[4], ob.p[5], ob.p[6], ob.p[7], ob.p[8],
-                             testMinT, t, bb, gg)) {
-                    float wt = world_t(ob, ro, time, to, td, t);
-                    if (wt < minT) {
-                        if (ANYHIT) return true;
-                        minT = wt;
-                        has = true;
-                        out.kind_index = (RT_KIND_TRIANGLE << 28) | tp.index;
-                        out.tri = 0;
-                        tmax = minT;
+                ar.set(ro, rd);
+                tmax = minT;
+            } else {
+                if (cur == RT_LINK_DONE) { finished = true; break; }   // traversal exhausted
+                top_slot = RT_LEAF_FIRST(cur);
+                top_remaining = leaf_count(S, cur, true);
+            }
+
+            // ---- prims of the current top-level leaf, in order (raytracer.cpp:548-745)
+            bool entered = false;
+            while (top_remaining != 0) {
+                const DTopPrim tp = S.top_prims[top_slot];
+                top_slot++;
+                top_remaining--;
+                const DObject& ob = S.objects[tp.obj];
+                V3 to, td;
+                float testMinT;
+                object_space_ray(ob, ro, rd, time, minT, to, td, testMinT);
+                if (tp.kind == RT_KIND_MESH) {
+                    if (ob.root_link == RT_LINK_DONE) continue;
+                    ActiveRay mr;
+                    mr.set(to, td);
+                    float te;
+                    if (!box_test(mr, ob.rminx, ob.rminy, ob.rminz, ob.rmaxx, ob.rmaxy, ob.rmaxz, testMinT, te)) continue;
+                    ar = mr;
+                    tmax = testMinT;
+                    cur_obj = tp.obj;
+                    cur_kind_index = (RT_KIND_MESH << 28) | tp.index;
+                    mesh_found = false;
+                    in_mesh = true;
+                    st.push(RT_LINK_SENTINEL, -1.0f);
+                    cur = ob.root_link;
+                    cur_t = te;
+                    entered = true;
+                    break;
+                } else if (tp.kind == RT_KIND_SPHERE) {
+                    ActiveRay sr;
+                    sr.set(to, td);
+                    float t;
+                    if (sphere_test(sr, ob.p[0], ob.p[1], ob.p[2], ob.p[3], testMinT, t)) {
+                        float wt = world_t(ob, ro, time, to, td, t);
+                        if (wt < minT) {
+                            if (ANYHIT) { fin = true; break; }
+                            minT = wt;
+                            has = true;
+                            out.kind_index = (RT_KIND_SPHERE << 28) | tp.index;
+                            out.tri = 0;
+                            tmax = minT;
+                        }
+                    }
+                } else {   // RT_KIND_TRIANGLE
+                    ActiveRay tr;
+                    tr.set(to, td);
+                    float t, bb, gg;
+                    if (tri_test(tr, ob.p[0], ob.p[1], ob.p[2], ob.p[3], ob.p[4], ob.p[5], ob.p[6], ob.p[7], ob.p[8],
+                                 testMinT, t, bb, gg)) {
+                        float wt = world_t(ob, ro, time, to, td, t);
+                        if (wt < minT) {
+                            if (ANYHIT) { fin = true; break; }
+                            minT = wt;
+                            has = true;
+                            out.kind_index = (RT_KIND_TRIANGLE << 28) | tp.index;
+                            out.tri = 0;
+                            tmax = minT;
+                        }
                     }
                 }
             }
+            if (fin) { finished = true; break; }
+            if (!entered) cur = st.pop(tmax, cur_t);
+        } while (0);
+
+        if (alive && finished) {
+            io.store(item, ANYHIT ? fin : has, out, minT);
+            alive = false;
+            in_mesh = false;
+            cur = RT_LINK_DONE;
+            st.sp = 0;
         }
-        if (!entered) cur = st.pop(tmax, cur_t);
     }
-    out.t = minT;
-    return ANYHIT ? false : has;
 }

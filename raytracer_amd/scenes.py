@@ -36,6 +36,58 @@ def displaced_sphere(n):
     return verts, faces
 
 
+def _displace(d):
+    """Radius of the displaced sphere in direction d (unit vectors [...,3]): the same closed form as
+    displaced_sphere, written in terms of the direction so that any tessellation can use it."""
+    th = np.arccos(np.clip(d[..., 1], -1.0, 1.0))
+    ph = np.arctan2(d[..., 2], d[..., 0]) % (2.0 * np.pi)
+    return 1.0 + 0.08 * np.sin(13 * th) * np.sin(11 * ph) + 0.03 * np.sin(41 * th + ph)
+
+
+def cube_sphere(g):
+    """Displaced unit sphere tessellated as a spherified cube: 6 faces of g x g quads -> 12 g^2 triangles of
+    near-uniform size (g=289 -> 1 002 252), no poles, no degenerate triangles — the triangle statistics of
+    a scanned PLY model rather than of a latitude/longitude grid.  Vertices are indexed by their integer
+    lattice position on the cube surface, so faces share edge vertices exactly (watertight).
+    Returns (verts float32 [6 g^2 + 2, 3], faces int32 [12 g^2, 3], 0-based)."""
+    idx = {}
+    pts = []
+
+    def vid(i, j, k):
+        key = (i, j, k)
+        v = idx.get(key)
+        if v is None:
+            v = idx[key] = len(pts)
+            pts.append(key)
+        return v
+
+    faces = []
+    r = range(g)
+    for axis in range(3):
+        for side in (0, g):
+            for a in r:
+                for b in r:
+                    def P(u, v):
+                        c = [0, 0, 0]
+                        c[axis] = side
+                        c[(axis + 1) % 3] = u
+                        c[(axis + 2) % 3] = v
+                        return vid(*c)
+                    q = (P(a, b), P(a + 1, b), P(a + 1, b + 1), P(a, b + 1))
+                    if side == 0:
+                        q = (q[0], q[3], q[2], q[1])      # outward orientation
+                    faces.append((q[0], q[1], q[2]))
+                    faces.append((q[0], q[2], q[3]))
+    c = np.asarray(pts, np.float64) * (2.0 / g) - 1.0
+    x, y, z = c[:, 0], c[:, 1], c[:, 2]
+    d = np.stack([x * np.sqrt(1 - y * y / 2 - z * z / 2 + y * y * z * z / 3),
+                  y * np.sqrt(1 - z * z / 2 - x * x / 2 + z * z * x * x / 3),
+                  z * np.sqrt(1 - x * x / 2 - y * y / 2 + x * x * y * y / 3)], -1)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    verts = (d * _displace(d)[:, None]).astype(np.float32)
+    return verts, np.asarray(faces, np.int32)
+
+
 def _mat_rows(m):
     return [float(v) for v in m]
 
@@ -218,18 +270,18 @@ def write_ply(path, verts, faces0):
 
 
 # ------------------------------------------------------------------ workloads
-def mesh_scene(grid=709, width=1920, height=1080, num_samples=1, name=None):
+def mesh_scene(grid=709, width=1920, height=1080, num_samples=1, name=None, tessellation="latlong"):
     """M2 (BASELINE.json configs[1]): one displaced-sphere mesh of 2*(grid-1)^2
     triangles (grid=709 -> 1 002 528) over a 2-triangle ground mesh, 2 point
     lights, diffuse materials, MaxRecursionDepth 0 => primary + 2 shadow rays per hit."""
-    s = SynthScene(name or f"mesh_{grid}")
+    s = SynthScene(name or f"mesh_{tessellation}_{grid}" if tessellation != "latlong" else name or f"mesh_{grid}")
     s.max_depth = 0
     s.ambient = (25, 25, 25)
     s.vertices = [(-6, -1.15, -6), (6, -1.15, -6), (6, -1.15, 6), (-6, -1.15, 6)]
     s.materials = [dict(ambient=(1, 1, 1), diffuse=(0.8, 0.7, 0.5), specular=(0.6, 0.6, 0.6), phong=30.0),
                    dict(ambient=(1, 1, 1), diffuse=(0.5, 0.6, 0.7), specular=(0.1, 0.1, 0.1), phong=5.0)]
     s.point_lights = [((4, 6, 5), (90000, 90000, 90000)), ((-5, 4, 2), (45000, 40000, 35000))]
-    verts, faces = displaced_sphere(grid)
+    verts, faces = cube_sphere(grid) if tessellation == "cube" else displaced_sphere(grid)
     s.meshes = [dict(verts=None, faces=np.array([[1, 3, 2], [1, 4, 3]], np.int32), material=2),
                 dict(verts=verts, faces=faces, material=1)]
     s.camera = dict(position=(0.4, 1.1, 4.2), gaze_point=(0, -0.05, 0), up=(0, 1, 0), fovy=32.0, near=1.0, width=width,
