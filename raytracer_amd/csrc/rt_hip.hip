@@ -81,7 +81,7 @@ struct rt_scene {
     // work memory
     Pool pool{};
     DevBuf b_ray0, b_ray1, b_hit0, b_hit1, b_nrm, b_link, b_color, b_shadow_rec, b_shadow_lit;
-    DevBuf b_ctl, b_spill, b_mt, b_fb, b_hits;
+    DevBuf b_ctl, b_spill, b_cand, b_mt, b_fb, b_hits;
     Control* h_ctl = nullptr;   // pinned
 
     // options
@@ -246,6 +246,27 @@ BvhLayout layout_bvh(const rt_bvh_node* nodes, uint32_t count, uint32_t leaf_bas
     return L;
 }
 
+// Subtree donation (rt_traverse.h) orders the hits of one ray by triangle slot, which is the visiting
+// order only if the depth-first, left-first walk meets the leaves with ascending first-prim index — true
+// for the reference's in-place partitioning builder (Bvh.h / raytracer.cpp:247-262), checked here for any caller.
+bool leaves_ascending(const rt_bvh_node* nodes, uint32_t count) {
+    if (count == 0) return true;
+    std::vector<uint32_t> stack{0};
+    int64_t next = -1;
+    while (!stack.empty()) {
+        const rt_bvh_node& n = nodes[stack.back()];
+        stack.pop_back();
+        if (n.prim_count > 0) {
+            if ((int64_t)n.left_or_first <= next) return false;
+            next = (int64_t)n.left_or_first + n.prim_count - 1;
+        } else {
+            stack.push_back((uint32_t)n.left_or_first + 1);
+            stack.push_back((uint32_t)n.left_or_first);
+        }
+    }
+    return true;
+}
+
 void fill_object_common(DObject& o, uint32_t flags, const float* M, const float* Minv, const float* mb, int material_id) {
     std::memset(&o, 0, sizeof(o));
     std::memcpy(o.M, M, 64);
@@ -265,9 +286,11 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
 
     // mesh BVHs
     std::vector<BvhLayout> mesh_layout(s->n_mesh_bvhs);
+    bool donate_ok = true;
     for (uint32_t b = 0; b < s->n_mesh_bvhs; b++) {
         const rt_mesh_bvh& mb = s->mesh_bvhs[b];
         mesh_layout[b] = layout_bvh(s->mesh_nodes + mb.node_offset, mb.node_count, mb.prim_offset, false, nodes, big);
+        if (!leaves_ascending(s->mesh_nodes + mb.node_offset, mb.node_count)) donate_ok = false;
         for (uint32_t p = 0; p < mb.prim_count; p++) {
             const uint32_t fi = s->mesh_prim_face[mb.prim_offset + p];
             const rt_face& f = s->faces[mb.face_offset + fi];
@@ -383,6 +406,7 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
     D.nodes = (const DNode4*)sc->b_nodes.p;
     D.big_leaves = (const DBigLeaf*)sc->b_big.p;
     D.n_big_leaves = (uint32_t)big.size();
+    D.donate_ok = donate_ok ? 1u : 0u;
     D.tris = (const DTri*)sc->b_tris.p;
     D.tri_shade = (const DTriShade*)sc->b_tri_shade.p;
     D.vnormals = (const float4*)sc->b_vnormals.p;
@@ -485,6 +509,9 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
     const int grid_trace = std::max(sc->blocks_closest, sc->blocks_shadow);
     if ((rc = sc->b_spill.ensure(spill_per_block * grid_trace))) return rc;
     uint2* spill = (uint2*)sc->b_spill.p;
+    // candidate hits of rays whose subtrees were traced by other lanes (rt_traverse.h): 64 x RT_CAND_MAX per wave
+    if ((rc = sc->b_cand.ensure((size_t)grid_trace * (RT_TRACE_BLOCK / 64) * 64 * RT_CAND_MAX * sizeof(uint4)))) return rc;
+    uint4* cand = (uint4*)sc->b_cand.p;
 
     const bool want_sync = stats != nullptr || (sc->opt_flags & RT_FLAG_TIMING) || D > 0;
     Timer tm{sc, st, (sc->opt_flags & RT_FLAG_TIMING) != 0};
@@ -531,7 +558,7 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         const int grid_flat = 2048;
         for (int d = 0; d <= D; d++) {
             if ((rc = tm.begin(TC_CLOSEST))) return rc;
-            k_trace_closest<<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, spill);
+            k_trace_closest<<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, spill, cand);
             if ((rc = tm.end())) return rc;
             if ((rc = tm.begin(TC_SHADE))) return rc;
             k_shade<<<grid_flat, 256, 0, st>>>(sc->ds, P, ctl, d);
@@ -539,7 +566,7 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
             if ((rc = tm.end())) return rc;
             if (sc->n_point_lights) {
                 if ((rc = tm.begin(TC_SHADOW))) return rc;
-                k_trace_shadow<<<sc->blocks_shadow, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, spill);
+                k_trace_shadow<<<sc->blocks_shadow, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, spill, cand);
                 if ((rc = tm.end())) return rc;
             }
         }
@@ -585,6 +612,25 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
                 d[5] ? (double)d[1] / d[5] : 0.0, d[5] ? (double)d[3] / d[5] : 0.0, d[5] ? 64.0 * d[0] / d[5] : 0.0,
                 d[5] ? 64.0 * d[2] / d[5] : 0.0, d[5] ? 64.0 * d[4] / d[5] : 0.0);
         // wall_clock64 ticks are 10 ns
+        {
+            static unsigned long long hw[8192][16];
+            if (hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_wave_dbg), sizeof(hw)) == hipSuccess) {
+                const int nw = std::min(8192, sc->blocks_closest * (RT_TRACE_BLOCK / 64));
+                std::vector<int> order(nw);
+                for (int i = 0; i < nw; i++) order[i] = i;
+                std::sort(order.begin(), order.end(), [&](int a, int b) { return hw[a][0] > hw[b][0]; });
+                double sum[16] = {0};
+                for (int i = 0; i < nw; i++) for (int k = 0; k < 15; k++) sum[k] += (double)hw[i][k];
+                fprintf(stderr, "[rt stats] per-wave mean: life %.0f us exhausted@%.0f | sched %.0f node %.0f tri %.0f big %.0f trans %.0f us | outer %.0f nodesteps %.0f tristeps %.0f donations %.1f coop %.1f rays %.0f\n",
+                        sum[0] * 0.01 / nw, sum[1] * 0.01 / nw, sum[2] * 0.01 / nw, sum[3] * 0.01 / nw, sum[4] * 0.01 / nw, sum[5] * 0.01 / nw, sum[6] * 0.01 / nw,
+                        sum[7] / nw, sum[8] / nw, sum[9] / nw, sum[10] / nw, sum[11] / nw, sum[12] / nw);
+                for (int r = 0; r < 6 && r < nw; r++) {
+                    const unsigned long long* o = hw[order[r]];
+                    fprintf(stderr, "[rt stats] wave %d: life %.0f us exhausted@%.0f | sched %.0f node %.0f tri %.0f big %.0f trans %.0f us | outer %llu nodesteps %llu (lanes %llu) tristeps %llu (lanes %llu) donations %llu coop %llu rays %llu\n",
+                            order[r], o[0] * 0.01, o[1] * 0.01, o[2] * 0.01, o[3] * 0.01, o[4] * 0.01, o[5] * 0.01, o[6] * 0.01, o[7], o[8], o[13], o[9], o[14], o[10], o[11], o[12]);
+                }
+            }
+        }
         fprintf(stderr, "[rt stats] closest timing: waves=%llu kernel span %.1f us, wave lifetime mean %.1f min %.1f max %.1f us\n",
                 d[13], (d[11] - ~d[10]) * 0.01, d[13] ? d[12] * 0.01 / d[13] : 0.0, (~d[15]) * 0.01, d[14] * 0.01);
     }
@@ -735,7 +781,7 @@ void rt_free_scene(rt_scene* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (DevBuf* b : {&s->b_big, &s->b_nodes, &s->b_tris, &s->b_tri_shade, &s->b_vnormals, &s->b_objects, &s->b_top_prims, &s->b_planes,
                       &s->b_materials, &s->b_lights, &s->b_ray0, &s->b_ray1, &s->b_hit0, &s->b_hit1, &s->b_nrm, &s->b_link,
-                      &s->b_color, &s->b_shadow_rec, &s->b_shadow_lit, &s->b_ctl, &s->b_spill, &s->b_mt, &s->b_fb, &s->b_hits})
+                      &s->b_color, &s->b_shadow_rec, &s->b_shadow_lit, &s->b_ctl, &s->b_spill, &s->b_cand, &s->b_mt, &s->b_fb, &s->b_hits})
         b->release();
     for (auto& e : s->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }

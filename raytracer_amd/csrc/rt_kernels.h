@@ -282,10 +282,12 @@ struct WaveWork {
 
 // LDS per wave: RT_STACK_LDS stack entries + RT_LEAF_QUEUE postponed leaves, 8 bytes each per lane.
 #define RT_LDS_ENTRIES (RT_STACK_LDS + RT_LEAF_QUEUE)
-__device__ __forceinline__ TraceStack make_stack(uint2* s_lds, uint2* spill, const WaveWork& ww) {
+__device__ __forceinline__ TraceStack make_stack(uint2* s_lds, uint32_t* s_cnt, uint2* spill, uint4* cand, const WaveWork& ww) {
     TraceStack st;
     st.lds = s_lds + ww.wave * (RT_LDS_ENTRIES * 64);
     st.q = st.lds + RT_STACK_LDS * 64;
+    st.cand_cnt = s_cnt + ww.wave * 64;
+    st.cand = cand + ((size_t)blockIdx.x * (RT_TRACE_BLOCK / 64) + ww.wave) * (size_t)(64 * RT_CAND_MAX);
     size_t wave_slot = (size_t)blockIdx.x * (RT_TRACE_BLOCK / 64) + ww.wave;
     st.spill = spill + wave_slot * (size_t)((RT_STACK_MAX - RT_STACK_LDS) * 64);
     st.lane = ww.lane;
@@ -296,6 +298,10 @@ __device__ __forceinline__ TraceStack make_stack(uint2* s_lds, uint2* spill, con
 #endif
     return st;
 }
+
+#ifdef RT_TRACE_STATS
+__device__ unsigned long long g_wave_dbg[8192][16];   // per wave of k_trace_closest (diagnostic build)
+#endif
 
 // FindClosestHit's search part (raytracer.cpp:405-444) for generation `gen`.
 struct ClosestIO {
@@ -333,10 +339,11 @@ struct ClosestIO {
     }
 };
 
-__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_closest(DScene S, Pool P, Control* ctl, int gen, uint2* spill) {
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_closest(DScene S, Pool P, Control* ctl, int gen, uint2* spill, uint4* cand) {
     __shared__ uint2 s_lds[(RT_TRACE_BLOCK / 64) * RT_LDS_ENTRIES * 64];
+    __shared__ uint32_t s_cnt[RT_TRACE_BLOCK];
     WaveWork ww;
-    TraceStack st = make_stack(s_lds, spill, ww);
+    TraceStack st = make_stack(s_lds, s_cnt, spill, cand, ww);
     const uint32_t begin = ctl->gstart[gen], end = ctl->gstart[gen + 1];
 #ifdef RT_TRACE_STATS
     TraceStatsAcc acc = {};
@@ -356,6 +363,23 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_closest(
         const unsigned long long clk_end = wall_clock64();
         atomicMax(&ctl->dbg[10], ~clk_start); atomicMax(&ctl->dbg[11], clk_end); atomicAdd(&ctl->dbg[12], clk_end - clk_start); atomicAdd(&ctl->dbg[13], 1ull);
         atomicMax(&ctl->dbg[14], clk_end - clk_start); atomicMax(&ctl->dbg[15], ~(clk_end - clk_start));
+        const uint32_t wg = blockIdx.x * (RT_TRACE_BLOCK / 64) + ww.wave;
+        if (wg < 8192) {
+            unsigned long long* o = g_wave_dbg[wg];
+            o[0] = clk_end - clk_start; o[1] = acc.clk_exhausted ? acc.clk_exhausted - clk_start : 0; o[2] = acc.t_sched; o[3] = acc.t_node;
+            o[4] = acc.t_tri; o[5] = acc.t_big; o[6] = acc.t_trans; o[7] = 0; o[8] = 0; o[9] = 0;
+            o[10] = acc.n_donations; o[11] = acc.n_coop; o[12] = traced; o[13] = 0; o[14] = 0; o[15] = clk_start;
+        }
+    }
+    {   // step counts live in whichever lane was first active: sum them per wave (after lane 0's plain stores above)
+        __threadfence();
+        const uint32_t wg = blockIdx.x * (RT_TRACE_BLOCK / 64) + ww.wave;
+        if (wg < 8192) {
+            unsigned long long* o = g_wave_dbg[wg];
+            if (acc.wave_outer) atomicAdd(&o[7], acc.wave_outer);
+            if (acc.wave_node_steps) { atomicAdd(&o[8], acc.wave_node_steps); atomicAdd(&o[13], acc.lane_node_steps); }
+            if (acc.wave_tri_steps) { atomicAdd(&o[9], acc.wave_tri_steps); atomicAdd(&o[14], acc.lane_tri_steps); }
+        }
     }
 #endif
     if (traced && ww.lane == 0) atomicAdd(gen == 0 ? &ctl->rays_primary : &ctl->rays_secondary, traced);
@@ -391,10 +415,11 @@ struct ShadowIO {
     __device__ __forceinline__ void store(uint32_t i, bool shadow, const HitOut&, float) const { P.shadow_lit[i] = shadow ? 0 : 1; }
 };
 
-__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_shadow(DScene S, Pool P, Control* ctl, int gen, uint2* spill) {
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_shadow(DScene S, Pool P, Control* ctl, int gen, uint2* spill, uint4* cand) {
     __shared__ uint2 s_lds[(RT_TRACE_BLOCK / 64) * RT_LDS_ENTRIES * 64];
+    __shared__ uint32_t s_cnt[RT_TRACE_BLOCK];
     WaveWork ww;
-    TraceStack st = make_stack(s_lds, spill, ww);
+    TraceStack st = make_stack(s_lds, s_cnt, spill, cand, ww);
     const uint32_t begin = ctl->sstart[gen], end = ctl->sstart[gen + 1];
 #ifdef RT_TRACE_STATS
     TraceStatsAcc acc = {};   // the shadow kernel's counts are not reported, but the loop writes through st.acc

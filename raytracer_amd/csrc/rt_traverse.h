@@ -48,7 +48,7 @@
 #include "rt_device.h"
 
 #ifndef RT_STACK_LDS
-#define RT_STACK_LDS 12          // entries per lane kept in LDS
+#define RT_STACK_LDS 11          // entries per lane kept in LDS
 #endif
 #ifndef RT_LEAF_QUEUE
 #define RT_LEAF_QUEUE 8          // mesh leaves a lane may postpone before the wave switches to triangle tests
@@ -62,8 +62,26 @@
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 16         // idle lanes of a wave that trigger a refill from the generation's cursor
 #endif
+#ifndef RT_STRIP
+#define RT_STRIP 8               // closest-hit: consecutive items of a 64-item block handed out together (divides 64)
+#endif
+#ifndef RT_STRIP_ANY
+#define RT_STRIP_ANY 64          // any-hit: shadow slots of one record are neighbours and differ in direction; keep blocks whole
+#endif
+#ifndef RT_REFILL_MIN_ANY
+#define RT_REFILL_MIN_ANY 32
+#endif
+#ifndef RT_DONATE_PASSES
+#define RT_DONATE_PASSES 4       // stack entries a busy lane may give away per round (helpers included, so a subtree fans out)
+#endif
+#ifndef RT_REFILL_PATIENCE
+#define RT_REFILL_PATIENCE 2     // rounds a wave waits for RT_REFILL_MIN idle lanes before it refills the ones it has
+#endif
 #ifndef RT_COOP_MIN
-#define RT_COOP_MIN 64           // a leaf with at least this many triangles is tested by the whole wave for one ray
+#define RT_COOP_MIN 32           // a leaf with at least this many triangles can be tested by the whole wave for one ray
+#endif
+#ifndef RT_CAND_MAX
+#define RT_CAND_MAX 16           // candidate hits a ray can collect from donated subtrees before it falls back to tracing alone
 #endif
 #define RT_STACK_MAX 64          // the reference's stack[64] (raytracer.cpp:533,766)
 #define RT_TRACE_BLOCK 256       // 4 waves per workgroup
@@ -73,10 +91,13 @@
 #ifdef RT_TRACE_STATS
 struct TraceStatsAcc {
     unsigned long long wave_node_steps, lane_node_steps, wave_tri_steps, lane_tri_steps, wave_outer, lane_rays, wave_batches, wave_pops, lane_pops;
+    unsigned long long t_sched, t_node, t_tri, t_big, t_trans, clk_exhausted, n_donations, n_coop, n_replays;
 };
+#define RT_CLK(v) const unsigned long long v = wall_clock64()
 #define RT_STAT(x) x
 #else
 #define RT_STAT(x)
+#define RT_CLK(v)
 #endif
 
 typedef float f4a __attribute__((ext_vector_type(4)));
@@ -86,6 +107,8 @@ struct TraceStack {
     uint2*    lds;        // [RT_STACK_LDS][64] for this wave: (link, bits of tEnter)
     uint2*    spill;      // [(RT_STACK_MAX-RT_STACK_LDS)][64] for this wave (global)
     uint2*    q;          // [RT_LEAF_QUEUE][64] postponed mesh leaves, in visiting order: (link, bits of tEnter)
+    uint32_t* cand_cnt;   // [64] (LDS) candidates collected for the ray owned by lane k
+    uint4*    cand;       // [64][RT_CAND_MAX] (global) for this wave: (triangle slot, t bits, leaf tEnter bits, -)
     uint32_t  lane;
     uint32_t  sp;
     uint32_t  overflow;
@@ -109,7 +132,14 @@ struct TraceStack {
         lds[sp * 64 + lane] = make_uint2(link, __float_as_uint(t));
         sp++;
     }
-    // Pop the next entry the reference would not cull (see file header).
+    __device__ __forceinline__ uint2 read_at(uint32_t pos) const {
+        return pos < RT_STACK_LDS ? lds[pos * 64 + lane] : spill[(pos - RT_STACK_LDS) * 64 + lane];
+    }
+    __device__ __forceinline__ void write_at(uint32_t pos, uint2 e) {
+        if (pos < RT_STACK_LDS) lds[pos * 64 + lane] = e; else spill[(pos - RT_STACK_LDS) * 64 + lane] = e;
+    }
+    // Pop the next entry the reference would not cull (see file header).  Slots whose subtree
+    // was given to another lane hold RT_LINK_NONE and are skipped.
     __device__ __forceinline__ uint32_t pop(float tmax, float& t_out) {
         while (sp > 0) {
             --sp;
@@ -121,7 +151,7 @@ struct TraceStack {
                 asm volatile("" : "+v"(e.x));   // keep the rare global path a branch (else both merge into one flat load)
             }
             const float t = __uint_as_float(e.y);
-            if (!((tmax < t) || (t == 0.0f && tmax <= 0.0f))) { t_out = t; return e.x; }
+            if (e.x != RT_LINK_NONE && !((tmax < t) || (t == 0.0f && tmax <= 0.0f))) { t_out = t; return e.x; }
         }
         return RT_LINK_DONE;
     }
@@ -274,13 +304,31 @@ __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int src) { return (ui
 // The persistent trace loop of one wave: FindClosestHit's BVH part (ANYHIT = false)
 // or InShadow's (ANYHIT = true) for the items [begin, end) of a generation.
 //
-// Scheduling: the 64 lanes are 64 ray slots.  A lane whose
-// ray is finished stores its result and goes idle; when RT_REFILL_MIN lanes are
-// idle the wave takes that many consecutive items from the generation's cursor
-// (one atomic) and hands them to the idle lanes.  So a wave is not bound to the
-// slowest ray of a fixed 64-ray batch (on the 1M-triangle frame the slowest batch
-// took 2.3 ms, three times the mean lifetime of a wave), while refilling in runs
-// keeps neighbouring pixels together.
+// Scheduling.  The 64 lanes are 64 ray slots.
+//  * Refill: a lane whose ray is finished stores its result and goes idle; when
+//    RT_REFILL_MIN lanes are idle the wave takes that many consecutive items from the
+//    generation's cursor (one atomic) and hands them to the idle lanes.  So a wave is
+//    not bound to the slowest ray of a fixed 64-ray batch, while refilling in runs
+//    keeps neighbouring pixels together.
+//  * Subtree donation: once the cursor is exhausted, idle lanes take over the
+//    bottom-most entry of a busy lane's mesh-level stack (the subtree the busy lane
+//    would reach LAST).  The OWNER of the ray keeps the reference's exact sequential
+//    state for the part it traverses itself, which precedes every donated subtree in
+//    visiting order.  A HELPER traverses its subtree with a bound b that starts at the
+//    donor's bound and RECORDS every triangle it would accept, (triangle, t, tEnter of
+//    its leaf), lowering b only when t >= tEnter.  b is then never below the minT the
+//    reference has at the same point (by induction over the visiting order: the
+//    reference either accepts the same triangle, or rejects it because minT <= t, or
+//    culls the leaf because minT < tEnter <= t), so every triangle the reference
+//    accepts inside the subtree is among the recorded ones (box and triangle tests
+//    are monotone in the bound).  When the owner's own part and all helpers are done,
+//    the owner replays the candidates in visiting order (= ascending triangle slot:
+//    the builder partitions the primitive array in place, raytracer.cpp:247-262, and
+//    the left child is visited first) with the reference's rule: skip if minT culls
+//    the leaf box, accept if t < minT.  That is the reference's result exactly; what
+//    changes is that one long ray is traced by many lanes (the slowest ray of the
+//    1M-triangle frame takes ~1000 sequential steps, longer than the rest of the
+//    kernel).  A ray with more than RT_CAND_MAX candidates re-traverses the mesh alone.
 //
 // IO::load(item, o, d, time, minT, has, out) -> int  sets up the ray (plane loop
 //   included, raytracer.cpp:423-435 / :1022-1028) and returns 2, or stores a final
@@ -291,12 +339,17 @@ template <bool ANYHIT, class IO>
 __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32_t end, uint32_t* cursor, TraceStack& st,
                                  unsigned long long& traced) {
     constexpr uint32_t QCAP = ANYHIT ? RT_LEAF_QUEUE_ANY : RT_LEAF_QUEUE;
+    constexpr uint32_t STRIP = ANYHIT ? RT_STRIP_ANY : RT_STRIP;
+    constexpr uint32_t REFILL_MIN = ANYHIT ? RT_REFILL_MIN_ANY : RT_REFILL_MIN;
+    static_assert(64 % STRIP == 0, "strips tile a 64-item block");
     static_assert(RT_LEAF_QUEUE_ANY <= RT_LEAF_QUEUE, "the LDS queue is sized by RT_LEAF_QUEUE");
     const uint32_t lane = st.lane;
     const uint64_t lanes_below = (1ull << lane) - 1ull;
 
-    // ---- per-lane ray slot
-    bool alive = false;
+    // ---- per-lane slot: a ray this lane owns, or a donated subtree of lane `home`'s ray
+    bool alive = false;          // traversing (owner or helper)
+    bool helper = false;
+    uint32_t home = lane;
     uint32_t item = 0;
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, 0);
     float time = 0.f, minT = 0.f;
@@ -316,23 +369,64 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
     uint32_t qn = 0;             // postponed leaves in the queue
     uint32_t cur = RT_LINK_DONE;
     float cur_t = 0.f;           // box entry distance of `cur`
-    bool exhausted = false;      // wave-uniform: the cursor has passed `end`
+    uint32_t don_next = 0;       // stack slot of the bottom-most mesh-level entry not yet given away
+    bool donated = false;        // owner: subtrees of the mesh traversal in flight were given away
+    bool no_donate = false;      // owner: re-traversing alone after a candidate overflow
+    bool cancel_req = false;     // any-hit found for ray `home`: everybody working on it stops
+    bool help_active = false;    // owner: a helper is still working for this lane
+    bool exhausted = false;      // wave-uniform: the cursor has passed the last item
+    // Order in which the cursor hands out the items.  Items come in blocks of 64 neighbours (one 8x8 pixel
+    // tile for primary rays).  Expensive rays cluster (silhouettes): a wave that takes a whole expensive
+    // block is busy three times longer than the average wave and the kernel waits for it.  So the cursor
+    // walks the blocks strip by strip: strip 0 (RT_STRIP items) of every block, then strip 1 of every block,
+    // ...  A 64-lane refill then takes one strip from each of 64/RT_STRIP neighbouring blocks (for primary
+    // rays a line of pixels), and the rays of one block are spread over 64/RT_STRIP waves and moments.
+    const uint32_t n_blocks = (end - begin + 63u) / 64u, n_padded = n_blocks * 64u;
+    uint32_t stale = 0;          // wave-uniform: rounds with idle lanes since the last refill
     st.sp = 0;
 
     for (;;) {
-        // ---- refill idle lanes (wave-uniform control flow)
+        RT_CLK(c0);
+        // ---- an any-hit verdict reached for a split ray ends the ray and all its helpers (wave-uniform control flow)
+        if (ANYHIT) {
+            uint64_t cm = __ballot(cancel_req);
+            if (cm != 0) {
+                uint64_t cancel_homes = 0;
+                while (cm != 0) {
+                    const int src = __ffsll((long long)cm) - 1;
+                    cm &= cm - 1;
+                    cancel_homes |= 1ull << lane_bcast(home, src);
+                }
+                cancel_req = false;
+                if (alive && ((cancel_homes >> home) & 1ull)) {
+                    if (!helper) io.store(item, true, out, minT);
+                    alive = false; helper = false; in_mesh = false; donated = false; no_donate = false;
+                    cur = RT_LINK_DONE; st.sp = 0; home = lane;
+                }
+            }
+        }
+
+        // ---- refill idle lanes
         if (!exhausted) {
             const uint64_t idle = __ballot(!alive);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
-            if (n_idle >= RT_REFILL_MIN) {
+            // A wave that keeps a few idle lanes for RT_REFILL_PATIENCE rounds refills them anyway: they
+            // would otherwise wait for the slowest rays, and the attempt is also how the wave learns that
+            // the cursor is drained (from then on idle lanes help the busy ones, see subtree donation).
+            stale = n_idle != 0 ? stale + 1 : 0;
+            if (n_idle >= REFILL_MIN || stale > RT_REFILL_PATIENCE) {
+                stale = 0;
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(cursor, n_idle);
-                base = begin + (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (base + n_idle >= end) exhausted = true;
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base + n_idle >= n_padded) { exhausted = true; RT_STAT(st.acc->clk_exhausted = wall_clock64();) }
                 int got = 0;
                 if (!alive) {
-                    const uint32_t i = base + (uint32_t)__popcll(idle & lanes_below);
-                    if (i < end) {
+                    // cursor value -> item: strip-interleaved over the 64-item blocks (see above)
+                    const uint32_t c = base + (uint32_t)__popcll(idle & lanes_below);
+                    const uint32_t strip = c / STRIP, within = c % STRIP;
+                    const uint32_t i = begin + (strip % n_blocks) * 64u + (strip / n_blocks) * STRIP + within;
+                    if (c < n_padded && i < end) {
                         item = i;
                         got = io.load(i, ro, rd, time, minT, has, out);
                     }
@@ -340,8 +434,12 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 traced += __popcll(__ballot(got != 0));
                 if (got == 2) {
                     alive = true;
+                    helper = false;
+                    home = lane;
                     st.sp = 0;
                     in_mesh = false;
+                    donated = false;
+                    no_donate = false;
                     qn = 0;
                     ar.set(ro, rd);
                     tmax = minT;
@@ -361,7 +459,75 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             continue;
         }
 
+        // ---- subtree donation to idle lanes
+#ifdef RT_SPLIT_ALWAYS
+        const bool split_now = S.donate_ok != 0;     // test build: exercise the donation path all the time
+#else
+        const bool split_now = exhausted && S.donate_ok != 0;
+#endif
+        if (split_now) {
+            uint64_t idle = __ballot(!alive);
+            for (int pass = 0; pass < RT_DONATE_PASSES && idle != 0; pass++) {
+            uint64_t donors = __ballot(alive && in_mesh && !no_donate && don_next < st.sp);
+            if (donors == 0) break;
+            while (idle != 0 && donors != 0) {
+                const int d = __ffsll((long long)donors) - 1;
+                donors &= donors - 1;                      // one entry per donor per round
+                uint32_t dl = RT_LINK_NONE;
+                float dt = 0.f;
+                if ((int)lane == d) {
+                    const uint2 e = st.read_at(don_next);
+                    st.write_at(don_next, make_uint2(RT_LINK_NONE, 0u));
+                    don_next++;
+                    dl = e.x;
+                    dt = __uint_as_float(e.y);
+                    if (dl != RT_LINK_NONE && ((tmax < dt) || (dt == 0.0f && tmax <= 0.0f))) dl = RT_LINK_NONE;   // culled by now
+                }
+                dl = lane_bcast(dl, d);
+                if (dl == RT_LINK_NONE) continue;
+                RT_STAT(st.acc->n_donations++;)
+                const int h = __ffsll((long long)idle) - 1;
+                idle &= idle - 1;
+                const uint32_t d_home = lane_bcast(home, d), d_obj = lane_bcast(cur_obj, d);
+                const float b_t = lane_bcast(dt, d), b_tmax = lane_bcast(tmax, d);
+                const float b_ox = lane_bcast(ar.ox, d), b_oy = lane_bcast(ar.oy, d), b_oz = lane_bcast(ar.oz, d);
+                const float b_dx = lane_bcast(ar.dx, d), b_dy = lane_bcast(ar.dy, d), b_dz = lane_bcast(ar.dz, d);
+                const float b_ix = lane_bcast(ar.ix, d), b_iy = lane_bcast(ar.iy, d), b_iz = lane_bcast(ar.iz, d);
+                if ((int)lane == d && !helper && !donated) {
+                    donated = true;
+                    st.cand_cnt[lane] = 0;
+                }
+                if ((int)lane == h) {
+                    alive = true;
+                    helper = true;
+                    home = d_home;
+                    cur_obj = d_obj;
+                    ar.ox = b_ox; ar.oy = b_oy; ar.oz = b_oz; ar.dx = b_dx; ar.dy = b_dy; ar.dz = b_dz;
+                    ar.ix = b_ix; ar.iy = b_iy; ar.iz = b_iz;
+                    tmax = b_tmax;
+                    in_mesh = true;
+                    mesh_found = false;
+                    qn = 0;
+                    st.sp = 0;
+                    st.push(RT_LINK_SENTINEL, -1.0f);
+                    don_next = st.sp;
+                    cur = dl;
+                    cur_t = b_t;
+                }
+            }
+            }
+            // which owners still have helpers at work
+            uint64_t hm = __ballot(alive && helper), active_homes = 0;
+            while (hm != 0) {
+                const int src = __ffsll((long long)hm) - 1;
+                hm &= hm - 1;
+                active_homes |= 1ull << lane_bcast(home, src);
+            }
+            help_active = ((active_homes >> lane) & 1ull) != 0;
+        }
+
         // ---- node phase: collapsed interior records of either level; mesh leaves are queued
+        RT_CLK(c1);
         RT_STAT(if (st.lane == __ffsll((long long)__ballot(1)) - 1) st.acc->wave_outer++;)
         for (;;) {
             // A lane can make progress here while it sits on an interior record, or on a mesh
@@ -409,8 +575,35 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             }
         }
 
+        RT_CLK(c2);
+        // A triangle of the mesh in flight passed the test with bound tmax (leaf box entry te):
+        // the owner accepts it as the reference does; a helper records it (see the header).
+        // Returns true when the lane is finished with its ray / subtree (any-hit).
+        auto accept = [&](uint32_t ti, float t, float bb, float gg, float te) -> bool {
+            if (helper) {
+                const uint32_t slot = atomicAdd(&st.cand_cnt[home], 1u);
+                if (slot < RT_CAND_MAX) st.cand[home * RT_CAND_MAX + slot] = make_uint4(ti, __float_as_uint(t), __float_as_uint(te), 0u);
+                if (t >= te) tmax = t;
+            } else {
+                tmax = t;
+                mesh_found = true;
+                mesh_tri = ti;
+                mesh_beta = bb;
+                mesh_gamma = gg;
+            }
+            if (ANYHIT) {
+                // Untransformed mesh: worldT == t < testMinT == minT, so the
+                // reference's verdict is already known.
+                if (!(S.objects[cur_obj].flags & RT_OBJ_HAS_TRANSFORM)) {
+                    if (helper || donated) cancel_req = true;
+                    return true;
+                }
+            }
+            return false;
+        };
+
         // ---- triangle phase: the postponed leaves, in visiting order (raytracer.cpp:781-798)
-        bool fin = false;        // this lane's ray is finished (ANYHIT: with verdict "in shadow")
+        bool fin = false;        // this lane's ray / subtree is finished by an any-hit
         for (uint32_t qi = 0; qi < qn && !fin; qi++) {
             const uint2 qe = st.q[qi * 64 + st.lane];
             const uint32_t link = qe.x;
@@ -426,34 +619,29 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 const float tc = tp[8];
                 float t, bb, gg;
                 if (tri_test(ar, ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w, tc, tmax, t, bb, gg)) {
-                    tmax = t;
-                    mesh_found = true;
-                    mesh_tri = ti;
-                    mesh_beta = bb;
-                    mesh_gamma = gg;
-                    if (ANYHIT) {
-                        // Untransformed mesh: worldT == t < testMinT == minT, so the
-                        // reference's verdict is already known.
-                        if (!(S.objects[cur_obj].flags & RT_OBJ_HAS_TRANSFORM)) { fin = true; break; }
-                    }
+                    if (accept(ti, t, bb, gg, te)) { fin = true; break; }
                 }
             }
         }
         qn = 0;
+        RT_CLK(c3);
 
         // ---- a big leaf (>= RT_LEAF_BIG triangles, raytracer.cpp:183: an unsplittable node) waiting at `cur`.
         // It follows the queued leaves in visiting order.  Below RT_COOP_MIN triangles the lane tests it
-        // alone; from RT_COOP_MIN on the whole wave tests it for that lane, 64 triangles per step: the
+        // alone; larger ones (from RT_COOP_MIN on, unless many lanes wait with one) the whole wave tests for that lane, 64 triangles per step: the
         // sequential scan `if (t < minT) minT = t` ends at the first triangle that attains the smallest
         // t below the incoming bound, which is what the (t, index) minimum over the lanes selects.
         bool big = alive && !fin && in_mesh && is_big_leaf_link(cur);
         if (big && ((tmax < cur_t) || (cur_t == 0.0f && tmax <= 0.0f))) { big = false; cur = st.pop(tmax, cur_t); }
-        if (__any(big)) {
+        const uint64_t big_lanes = __ballot(big);
+        if (big_lanes != 0) {
+            // the whole wave pays ~3 steps per leaf it tests together; a lane alone pays one step per triangle
+            const uint32_t coop_min = max((uint32_t)RT_COOP_MIN, 3u * (uint32_t)__popcll(big_lanes));
             uint32_t big_first = 0, big_n = 0;
             if (big) {
                 big_first = RT_LEAF_FIRST(cur);
                 big_n = leaf_count(S, cur, false);
-                if (big_n < RT_COOP_MIN) {
+                if (big_n < coop_min) {
                     uint32_t ti = big_first;
                     for (uint32_t n = big_n; n != 0; n--, ti++) {
                         const float* tp = reinterpret_cast<const float*>(&S.tris[ti]);
@@ -461,22 +649,16 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                         const float tc = tp[8];
                         float t, bb, gg;
                         if (tri_test(ar, ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w, tc, tmax, t, bb, gg)) {
-                            tmax = t;
-                            mesh_found = true;
-                            mesh_tri = ti;
-                            mesh_beta = bb;
-                            mesh_gamma = gg;
-                            if (ANYHIT) {
-                                if (!(S.objects[cur_obj].flags & RT_OBJ_HAS_TRANSFORM)) { fin = true; break; }
-                            }
+                            if (accept(ti, t, bb, gg, cur_t)) { fin = true; break; }
                         }
                     }
                 }
             }
-            uint64_t coop = __ballot(big && big_n >= RT_COOP_MIN);
+            uint64_t coop = __ballot(big && big_n >= coop_min);
             while (coop != 0) {                      // wave-uniform; every lane (idle ones too) takes part
                 const int src = __ffsll((long long)coop) - 1;
                 coop &= coop - 1;
+                RT_STAT(st.acc->n_coop++;)
                 ActiveRay br;
                 br.ox = lane_bcast(ar.ox, src); br.oy = lane_bcast(ar.oy, src); br.oz = lane_bcast(ar.oz, src);
                 br.dx = lane_bcast(ar.dx, src); br.dy = lane_bcast(ar.dy, src); br.dz = lane_bcast(ar.dz, src);
@@ -505,14 +687,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     const int win = __ffsll((long long)__ballot(best_i == red_i)) - 1;
                     const float wb = lane_bcast(best_b, win), wg = lane_bcast(best_g, win);
                     if ((int)lane == src) {
-                        tmax = red_t;
-                        mesh_found = true;
-                        mesh_tri = red_i;
-                        mesh_beta = wb;
-                        mesh_gamma = wg;
-                        if (ANYHIT) {
-                            if (!(S.objects[cur_obj].flags & RT_OBJ_HAS_TRANSFORM)) fin = true;
-                        }
+                        if (accept(red_i, red_t, wb, wg, cur_t)) fin = true;
                     }
                 }
             }
@@ -520,6 +695,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         }
 
         // ---- per-lane transitions between the levels
+        RT_CLK(c4);
         bool finished = fin;
         if (alive && !fin) do {
             if (in_mesh) {
@@ -528,19 +704,64 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     if ((cur & RT_LINK_LEAF) && ((tmax < cur_t) || (cur_t == 0.0f && tmax <= 0.0f))) cur = st.pop(tmax, cur_t);
                     break;
                 }
-                // ---- mesh traversal finished (IntersectMeshBVH returned), raytracer.cpp:596-620
+                if (helper) { finished = true; break; }        // the donated subtree is done
+                bool redo = false;
+                if (donated) {
+                    if (help_active) break;                    // wait for the helpers (cur stays on the sentinel)
+                    // ---- replay the helpers' candidates in visiting order with the reference's rule
+                    const uint32_t nc = st.cand_cnt[lane];
+                    if (nc > RT_CAND_MAX) {
+                        redo = true;                           // too many to keep: trace this mesh again, alone
+                    } else {
+                        uint32_t last = 0;
+                        bool first_round = true, from_cand = false;
+                        for (uint32_t r = 0; r < nc; r++) {
+                            uint4 best = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+                            for (uint32_t k = 0; k < nc; k++) {
+                                // written by other lanes of this wave: read past the (non-coherent) vector L1
+                                const uint32_t* cp = reinterpret_cast<const uint32_t*>(&st.cand[lane * RT_CAND_MAX + k]);
+                                uint4 c;
+                                c.x = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                c.y = __hip_atomic_load(cp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                c.z = __hip_atomic_load(cp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                c.w = 0u;
+                                if ((first_round || c.x > last) && c.x < best.x) best = c;
+                            }
+                            first_round = false;
+                            last = best.x;
+                            const float ct = __uint_as_float(best.y), cte = __uint_as_float(best.z);
+                            if ((tmax < cte) || (cte == 0.0f && tmax <= 0.0f)) continue;     // leaf culled by now
+                            if (ct < tmax) { tmax = ct; mesh_found = true; mesh_tri = best.x; from_cand = true; }
+                        }
+                        if (from_cand) {
+                            // beta / gamma of the winner: the same test on the same operands gives the same bits
+                            const float* tp = reinterpret_cast<const float*>(&S.tris[mesh_tri]);
+                            float t;
+                            (void)tri_test(ar, tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6], tp[7], tp[8], RT_INF, t, mesh_beta, mesh_gamma);
+                        }
+                    }
+                    donated = false;
+                }
                 in_mesh = false;
-                if (mesh_found) {
-                    const DObject& ob = S.objects[cur_obj];
-                    float wt = world_t(ob, ro, time, mk(ar.ox, ar.oy, ar.oz), mk(ar.dx, ar.dy, ar.dz), tmax);
-                    if (wt < minT) {
-                        if (ANYHIT) { fin = true; finished = true; break; }
-                        minT = wt;
-                        has = true;
-                        out.kind_index = cur_kind_index;
-                        out.tri = mesh_tri;
-                        out.beta = mesh_beta;
-                        out.gamma = mesh_gamma;
+                if (redo) {
+                    no_donate = true;
+                    top_slot--;
+                    top_remaining++;
+                } else {
+                    // ---- mesh traversal finished (IntersectMeshBVH returned), raytracer.cpp:596-620
+                    no_donate = false;
+                    if (mesh_found) {
+                        const DObject& ob = S.objects[cur_obj];
+                        float wt = world_t(ob, ro, time, mk(ar.ox, ar.oy, ar.oz), mk(ar.dx, ar.dy, ar.dz), tmax);
+                        if (wt < minT) {
+                            if (ANYHIT) { fin = true; finished = true; break; }
+                            minT = wt;
+                            has = true;
+                            out.kind_index = cur_kind_index;
+                            out.tri = mesh_tri;
+                            out.beta = mesh_beta;
+                            out.gamma = mesh_gamma;
+                        }
                     }
                 }
                 ar.set(ro, rd);
@@ -574,6 +795,8 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     mesh_found = false;
                     in_mesh = true;
                     st.push(RT_LINK_SENTINEL, -1.0f);
+                    don_next = st.sp;
+                    donated = false;
                     cur = ob.root_link;
                     cur_t = te;
                     entered = true;
@@ -616,11 +839,15 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         } while (0);
 
         if (alive && finished) {
-            io.store(item, ANYHIT ? fin : has, out, minT);
+            if (!helper) io.store(item, ANYHIT ? fin : has, out, minT);
             alive = false;
+            helper = false;        // `home` stays: a pending cancel_req names it
             in_mesh = false;
+            donated = false;
+            no_donate = false;
             cur = RT_LINK_DONE;
             st.sp = 0;
         }
+        RT_STAT({ const unsigned long long c5 = wall_clock64(); st.acc->t_sched += c1 - c0; st.acc->t_node += c2 - c1; st.acc->t_tri += c3 - c2; st.acc->t_big += c4 - c3; st.acc->t_trans += c5 - c4; })
     }
 }
