@@ -145,6 +145,29 @@ def test_full_size_properties_mesh1m(rt):
     assert (win == o_rgb).all() and (hw == o_hits).all()
 
 
+def test_subtree_donation_is_exact(rt, tmp_path):
+    """librt_hip_splittest.so is the same source built so that idle lanes take over subtrees of busy
+    rays from the first ray on (in the product that happens only once a generation's cursor is drained).
+    Its images and hit ids must equal the product's, which the tests above pin to the reference."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    specs = ["golden:hw2_two_berserkers", "golden:hw1_cornellbox_recursive", "golden:hw2_metal_glass_plates",
+             "golden:hw3_cornellbox_boxes_dynamic", "mesh:709:1920:1080", "inst:128:640:360"]
+    outs = {}
+    for so in ("librt_hip.so", "librt_hip_splittest.so"):
+        path = str(tmp_path / (so + ".npz"))
+        env = dict(os.environ, RT_HIP_SO=so)
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_render_npz.py"), path] + specs,
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[so] = np.load(path)
+    a, b = outs["librt_hip.so"], outs["librt_hip_splittest.so"]
+    for k in a.files:
+        assert (a[k] == b[k]).all(), k
+    name = "hw2_two_berserkers"
+    assert (b[f"golden:{name}/rgb"] == util.golden_image(name)).all()
+
+
 def test_errors_are_reported_not_thrown(rt):
     hs = util.golden_scene("hw3_cornellbox_area")        # area light: RNG drawn while shading (SURVEY 8f-1)
     ds = rt.DeviceScene(hs, 0)
