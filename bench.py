@@ -162,10 +162,21 @@ def main():
         bytes_closest = wb["closest_bytes_per_ray"] * rays[0]
         bytes_shadow = wb["shadow_bytes_per_ray"] * rays[2]
         dom = "k_trace_closest" if dur_closest >= dur_shadow else "k_trace_shadow"
+        # HBM-side bytes per launch of that kernel, from the committed rocprofv3 --pmc passes of this same
+        # command (a bench run cannot collect counters itself); only quoted for the workload they were taken on
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pt = json.load(f)
+            if world == 1 and args.grid == 709:
+                traffic = pt["mesh1m_1920x1080"][dom]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         ach = (bytes_closest / dur_closest if dom == "k_trace_closest" else bytes_shadow / dur_shadow) / 1e9
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": None,   # PMC-derived HBM bytes per launch: see profiles/ (collected in separate rocprofv3 --pmc runs)
+            "traffic": traffic,   # bytes per launch, FETCH_SIZE corrected as the microarch guide prescribes (profiles/pmc_traffic.json)
+            "algorithmic_bytes_per_launch": bytes_closest if dom == "k_trace_closest" else bytes_shadow,
             "algorithmic_bytes_per_ray": wb["closest_bytes_per_ray"] if dom == "k_trace_closest" else wb["shadow_bytes_per_ray"],
             "rays_per_launch": rays[0] if dom == "k_trace_closest" else rays[2],
             "avg_launch_ms": (dur_closest if dom == "k_trace_closest" else dur_shadow) * 1e3,
