@@ -16,6 +16,7 @@
 
 #include "rt.h"
 #include "rt_kernels.h"
+#include "rt_ordered.h"
 
 namespace {
 
@@ -69,19 +70,19 @@ struct rt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
     int n_cu = 256;
-    int blocks_closest = 0, blocks_shadow = 0;   // persistent grid sizes
+    int blocks_closest = 0, blocks_shadow = 0, blocks_ordered = 0;   // persistent grid sizes
 
     // device scene
-    DevBuf b_big, b_nodes, b_tris, b_tri_shade, b_vnormals, b_objects, b_top_prims, b_planes, b_materials, b_lights;
+    DevBuf b_big, b_nodes, b_tris, b_tri_shade, b_vnormals, b_objects, b_top_prims, b_planes, b_materials, b_lights, b_area_lights;
     DScene ds{};
     bool has_reflective = false;      // any material with type != None
     bool needs_sequential_rng = false;   // area lights or rough reflective materials (RNG drawn while shading)
-    uint32_t n_point_lights = 0;
+    uint32_t n_point_lights = 0, n_area_lights = 0;
 
     // work memory
     Pool pool{};
     DevBuf b_ray0, b_ray1, b_hit0, b_hit1, b_nrm, b_link, b_color, b_shadow_rec, b_shadow_lit;
-    DevBuf b_ctl, b_spill, b_cand, b_mt, b_fb, b_hits;
+    DevBuf b_ctl, b_spill, b_cand, b_mt, b_frames, b_fb, b_hits;
     Control* h_ctl = nullptr;   // pinned
 
     // options
@@ -396,7 +397,16 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
         lights[i].ix = s->point_lights[i].intensity[0]; lights[i].iy = s->point_lights[i].intensity[1]; lights[i].iz = s->point_lights[i].intensity[2];
     }
 
+    std::vector<DAreaLight> alights(s->n_area_lights);
+    for (uint32_t i = 0; i < s->n_area_lights; i++) {
+        const rt_area_light& a = s->area_lights[i];
+        alights[i] = DAreaLight{a.position[0], a.position[1], a.position[2], a.normal[0], a.normal[1], a.normal[2], a.size,
+                                a.radiance[0], a.radiance[1], a.radiance[2]};
+    }
+    sc->n_area_lights = s->n_area_lights;
+
     int rc;
+    if ((rc = upload_vec(sc->b_area_lights, alights))) return rc;
     if ((rc = upload_vec(sc->b_nodes, nodes)) || (rc = upload_vec(sc->b_tris, tris)) || (rc = upload_vec(sc->b_tri_shade, tshade)) ||
         (rc = upload_vec(sc->b_vnormals, vn)) || (rc = upload_vec(sc->b_objects, objects)) || (rc = upload_vec(sc->b_top_prims, top)) ||
         (rc = upload_vec(sc->b_big, big)) || (rc = upload_vec(sc->b_planes, planes)) || (rc = upload_vec(sc->b_materials, mats)) || (rc = upload_vec(sc->b_lights, lights)))
@@ -488,9 +498,6 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
     if (!d_rgb || stride < (size_t)w * 3) return fail(RT_ERR_INVALID, "bad output buffer / stride");
     const int N = cam->num_samples, sps = cam->samples_per_side;
     if (N < 1 || sps < 1 || N > 65535) return fail(RT_ERR_INVALID, "num_samples %d / samples_per_side %d not supported", N, sps);
-    if (sc->needs_sequential_rng)
-        return fail(RT_ERR_UNSUPPORTED, "scene draws random numbers while shading (area lights or Roughness > 0): "
-                                        "not built yet (SURVEY §8f-1)");
     int depth = sc->ds.max_depth;
     if (depth >= RT_MAX_GEN) return fail(RT_ERR_UNSUPPORTED, "MaxRecursionDepth %d exceeds %d", depth, RT_MAX_GEN - 1);
     HIPCHK(hipSetDevice(sc->device));
@@ -501,19 +508,19 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         return RT_OK;
     }
     const int D = sc->has_reflective ? depth : 0;   // without reflective materials no child ray is ever spawned
-    int rc = ensure_pool(sc);
+    int rc = sc->needs_sequential_rng ? RT_OK : ensure_pool(sc);
     if (rc) return rc;
     if ((rc = sc->b_ctl.ensure(sizeof(Control)))) return rc;
     Control* ctl = (Control*)sc->b_ctl.p;
     const size_t spill_per_block = (size_t)(RT_TRACE_BLOCK / 64) * (RT_STACK_MAX - RT_STACK_LDS) * 64 * sizeof(uint2);
-    const int grid_trace = std::max(sc->blocks_closest, sc->blocks_shadow);
+    const int grid_trace = std::max(std::max(sc->blocks_closest, sc->blocks_shadow), sc->blocks_ordered);
     if ((rc = sc->b_spill.ensure(spill_per_block * grid_trace))) return rc;
     uint2* spill = (uint2*)sc->b_spill.p;
     // candidate hits of rays whose subtrees were traced by other lanes (rt_traverse.h): 64 x RT_CAND_MAX per wave
     if ((rc = sc->b_cand.ensure((size_t)grid_trace * (RT_TRACE_BLOCK / 64) * 64 * RT_CAND_MAX * sizeof(uint4)))) return rc;
     uint4* cand = (uint4*)sc->b_cand.p;
 
-    const bool want_sync = stats != nullptr || (sc->opt_flags & RT_FLAG_TIMING) || D > 0;
+    const bool want_sync = stats != nullptr || (sc->opt_flags & RT_FLAG_TIMING) || D > 0 || sc->needs_sequential_rng;
     Timer tm{sc, st, (sc->opt_flags & RT_FLAG_TIMING) != 0};
     HIPCHK(hipMemsetAsync(ctl, 0, sizeof(Control), st));
 
@@ -535,11 +542,41 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
     uint64_t max_samples = std::min<uint64_t>(sc->opt_chunk_samples, D > 0 ? P.cap_records / 2 : P.cap_records);
     if (sc->n_point_lights) max_samples = std::min<uint64_t>(max_samples, P.cap_shadow / sc->n_point_lights);
     uint32_t tiles_per_chunk = (uint32_t)std::max<uint64_t>(1, max_samples / (64ull * N));
-    if ((uint64_t)tiles_per_chunk * 64 * N > P.cap_records) return fail(RT_ERR_OVERFLOW, "record pool too small for one 8x8 tile at %d spp", N);
+    if (!sc->needs_sequential_rng && (uint64_t)tiles_per_chunk * 64 * N > P.cap_records) return fail(RT_ERR_OVERFLOW, "record pool too small for one 8x8 tile at %d spp", N);
 
     uint32_t chunks = 0;
     uint64_t peak = 0;
     uint32_t tile = 0;
+    if (sc->needs_sequential_rng) {
+        // Shading draws random numbers (glossy materials, area lights): one lane per pixel walks the recursion
+        // depth-first so that the draws come in the reference's order (rt_ordered.h).  One launch, grid-stride.
+        const uint32_t n_idx = total_tiles * 64u;
+        const int grid = (int)std::min<uint32_t>((uint32_t)sc->blocks_ordered, (n_idx + RT_TRACE_BLOCK - 1) / RT_TRACE_BLOCK);
+        const size_t threads = (size_t)std::max(grid, 1) * RT_TRACE_BLOCK;
+        if ((rc = sc->b_mt.ensure(threads * (624 + (size_t)N) * 4))) return rc;
+        if ((rc = sc->b_frames.ensure(threads * (size_t)(depth + 1) * OF_COUNT * 4))) return rc;
+        OrderedArgs A;
+        A.cam = dc;
+        A.g = ChunkGeom{x0, y0, w, h, tiles_per_row, 0u, n_idx, row_parts, row_part};
+        A.area_lights = (const DAreaLight*)sc->b_area_lights.p;
+        A.n_area_lights = sc->n_area_lights;
+        A.mt_scratch = (uint32_t*)sc->b_mt.p;
+        A.frames = (float*)sc->b_frames.p;
+        A.inv_n = inv_n;
+        A.rgb = d_rgb;
+        A.row_stride = stride;
+        A.hit_ids = d_hits;
+        A.tri_shade = sc->ds.tri_shade;
+        if (grid > 0) {
+            if ((rc = tm.begin(TC_CLOSEST))) return rc;
+            k_pixel_ordered<<<grid, RT_TRACE_BLOCK, 0, st>>>(sc->ds, A, ctl, spill, cand);
+            if ((rc = tm.end())) return rc;
+            HIPCHK(hipGetLastError());
+        }
+        chunks = 1;
+        peak = n_idx;
+        tile = total_tiles;
+    }
     while (tile < total_tiles) {
         const uint32_t nt = std::min(tiles_per_chunk, total_tiles - tile);
         ChunkGeom g{x0, y0, w, h, tiles_per_row, tile, nt * 64u, row_parts, row_part};
@@ -600,6 +637,7 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
     if (want_sync) {
         HIPCHK(hipMemcpyAsync(sc->h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        if (sc->h_ctl->overflow & 8u) return fail(RT_ERR_HIP, "internal: a traced ray reached the wrong lane (rt_ordered.h)");
         if (sc->h_ctl->overflow & 4u) return fail(RT_ERR_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
         if (sc->h_ctl->overflow & 3u) return fail(RT_ERR_OVERFLOW, "ray pool overflow");
     }
@@ -701,6 +739,8 @@ int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out) {
     sc->blocks_closest = sc->n_cu * std::min(per_cu, cap);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_shadow, RT_TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     sc->blocks_shadow = sc->n_cu * std::min(per_cu, cap);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pixel_ordered, RT_TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    sc->blocks_ordered = sc->n_cu * std::min(per_cu, cap);
     *out = sc;
     return RT_OK;
 }
@@ -781,7 +821,7 @@ void rt_free_scene(rt_scene* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (DevBuf* b : {&s->b_big, &s->b_nodes, &s->b_tris, &s->b_tri_shade, &s->b_vnormals, &s->b_objects, &s->b_top_prims, &s->b_planes,
                       &s->b_materials, &s->b_lights, &s->b_ray0, &s->b_ray1, &s->b_hit0, &s->b_hit1, &s->b_nrm, &s->b_link,
-                      &s->b_color, &s->b_shadow_rec, &s->b_shadow_lit, &s->b_ctl, &s->b_spill, &s->b_cand, &s->b_mt, &s->b_fb, &s->b_hits})
+                      &s->b_color, &s->b_shadow_rec, &s->b_shadow_lit, &s->b_ctl, &s->b_spill, &s->b_cand, &s->b_mt, &s->b_frames, &s->b_area_lights, &s->b_fb, &s->b_hits})
         b->release();
     for (auto& e : s->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }

@@ -102,6 +102,7 @@ class SynthScene:
         self.vertices = []          # JSON VertexData (list of xyz)
         self.materials = []         # dicts for add_material
         self.point_lights = []      # (pos, intensity)
+        self.area_lights = []       # (pos, normal, size, radiance)
         self.meshes = []            # dict(verts|None, faces(0-based, into own verts or 1-based global if verts None), material, smooth, transform)
         self.instances = []         # dict(base (mesh ordinal), material, transform(list of ('t'|'s'|'r', args)), reset)
         self.spheres = []           # dict(center_vertex_id, radius, material, transform)
@@ -132,6 +133,8 @@ class SynthScene:
             b.add_material(**m)
         for pos, inten in self.point_lights:
             b.add_point_light(pos, inten)
+        for pos, nrm, size, rad in self.area_lights:
+            b.add_area_light(pos, nrm, size, rad)
         mesh_index = []
         for m in self.meshes:
             if m["verts"] is not None:
@@ -180,6 +183,8 @@ class SynthScene:
                  "PhongExponent": repr(float(m.get("phong", 1.0))), "RefractionIndex": repr(float(m.get("refraction_index", 0.0))),
                  "AbsorptionIndex": repr(float(m.get("absorption_index", 0.0))),
                  "AbsorptionCoefficient": fmt(m.get("absorption_coef", (0, 0, 0)))}
+            if m.get("roughness", 0.0) > 0:
+                d["Roughness"] = repr(float(np.float32(m["roughness"])))
             if m.get("type", 0) in names:
                 d["_type"] = names[m["type"]]
             mats.append(d)
@@ -238,6 +243,9 @@ class SynthScene:
                  "Materials": {"Material": mats},
                  "VertexData": {"_data": " ".join(fmt(v) for v in self.vertices), "_type": "xyz"},
                  "Objects": objects}
+        if self.area_lights:
+            scene["Lights"]["AreaLight"] = [{"_id": str(k + 1), "Position": fmt(p), "Normal": fmt(n), "Size": repr(float(np.float32(sz))),
+                                             "Radiance": fmt(r)} for k, (p, n, sz, r) in enumerate(self.area_lights)]
         trans = {}
         if tr_tab["t"]:
             trans["Translation"] = [{"_id": str(k + 1), "_data": fmt(a)} for k, a in enumerate(tr_tab["t"])]
@@ -343,4 +351,34 @@ def spheres_scene(width=256, height=256, num_samples=1, dof=False, name="spheres
     s.meshes = [dict(verts=None, faces=np.array([[5, 6, 7], [5, 7, 8]], np.int32), material=2)]
     s.camera = dict(position=(0.2, 0.8, 5.0), gaze_point=(0, 0, 0), up=(0, 1, 0), fovy=38.0, near=1.0, width=width, height=height,
                     num_samples=num_samples, aperture=0.15 if dof else 0.0, focus=5.0)
+    return s
+
+
+def glossy_area_scene(grid=48, width=320, height=200, num_samples=4, name=None):
+    """shading that draws random numbers.  A displaced-sphere mesh (rough conductor), a rough
+    dielectric instance of it, a rough mirror sphere and a diffuse floor under one area light and one point
+    light, depth 4, a few samples per pixel.  Every pixel's generator is consumed in recursion order."""
+    s = SynthScene(name or f"glossy_area_{grid}")
+    s.max_depth = 4
+    s.ambient = (20, 20, 20)
+    s.background = (8, 10, 14)
+    s.vertices = [(-8, -1.2, -8), (8, -1.2, -8), (8, -1.2, 8), (-8, -1.2, 8), (2.1, -0.4, 1.0)]
+    s.materials = [
+        dict(ambient=(1, 1, 1), diffuse=(0.6, 0.6, 0.55), specular=(0.2, 0.2, 0.2), phong=8.0),
+        dict(type=ffi.RT_MAT_CONDUCTOR, ambient=(0.1, 0.1, 0.1), diffuse=(0.1, 0.08, 0.02), specular=(0.8, 0.7, 0.3),
+             mirror=(1.0, 0.86, 0.57), phong=40.0, refraction_index=0.37, absorption_index=2.82, roughness=0.15),
+        dict(type=ffi.RT_MAT_DIELECTRIC, ambient=(0, 0, 0), diffuse=(0.02, 0.02, 0.02), specular=(0.3, 0.3, 0.3), mirror=(1, 1, 1),
+             phong=80.0, refraction_index=1.5, absorption_coef=(0.02, 0.01, 0.03), roughness=0.05),
+        dict(type=ffi.RT_MAT_MIRROR, ambient=(0.2, 0.2, 0.2), diffuse=(0.1, 0.1, 0.1), specular=(0.5, 0.5, 0.5),
+             mirror=(0.85, 0.85, 0.85), phong=60.0, roughness=0.3),
+    ]
+    s.point_lights = [((-5, 6, 4), (6000, 5600, 5200))]
+    s.area_lights = [((1.0, 5.0, 2.0), (0.1, -1.0, -0.2), 1.5, (9000, 9000, 9600))]
+    verts, faces = displaced_sphere(grid)
+    s.meshes = [dict(verts=None, faces=np.array([[1, 3, 2], [1, 4, 3]], np.int32), material=1),
+                dict(verts=verts, faces=faces, material=2, smooth=True)]
+    s.instances = [dict(base=1, material=3, transform=[("s", (0.7, 0.9, 0.7)), ("r", (25.0, 0, 1, 0)), ("t", (-2.2, -0.1, 0.6))])]
+    s.spheres = [dict(center=5, radius=0.8, material=4)]
+    s.camera = dict(position=(0.3, 1.4, 6.5), gaze_point=(0, -0.1, 0), up=(0, 1, 0), fovy=34.0, near=1.0, width=width,
+                    height=height, num_samples=num_samples)
     return s
