@@ -512,12 +512,13 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
     if (rc) return rc;
     if ((rc = sc->b_ctl.ensure(sizeof(Control)))) return rc;
     Control* ctl = (Control*)sc->b_ctl.p;
-    const size_t spill_per_block = (size_t)(RT_TRACE_BLOCK / 64) * (RT_STACK_MAX - RT_STACK_LDS) * 64 * sizeof(uint2);
-    const int grid_trace = std::max(std::max(sc->blocks_closest, sc->blocks_shadow), sc->blocks_ordered);
-    if ((rc = sc->b_spill.ensure(spill_per_block * grid_trace))) return rc;
+    // per-wave scratch of the trace loops, sized for the largest resident grid of any kernel that runs them
+    const size_t max_waves = std::max<size_t>((size_t)std::max(sc->blocks_closest, sc->blocks_shadow) * (RT_TRACE_BLOCK / 64),
+                                              (size_t)sc->blocks_ordered * (RT_ORDERED_BLOCK / 64));
+    if ((rc = sc->b_spill.ensure(max_waves * (RT_STACK_MAX - RT_STACK_LDS) * 64 * sizeof(uint2)))) return rc;
     uint2* spill = (uint2*)sc->b_spill.p;
     // candidate hits of rays whose subtrees were traced by other lanes (rt_traverse.h): 64 x RT_CAND_MAX per wave
-    if ((rc = sc->b_cand.ensure((size_t)grid_trace * (RT_TRACE_BLOCK / 64) * 64 * RT_CAND_MAX * sizeof(uint4)))) return rc;
+    if ((rc = sc->b_cand.ensure(max_waves * 64 * RT_CAND_MAX * sizeof(uint4)))) return rc;
     uint4* cand = (uint4*)sc->b_cand.p;
 
     const bool want_sync = stats != nullptr || (sc->opt_flags & RT_FLAG_TIMING) || D > 0 || sc->needs_sequential_rng;
@@ -551,8 +552,8 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         // Shading draws random numbers (glossy materials, area lights): one lane per pixel walks the recursion
         // depth-first so that the draws come in the reference's order (rt_ordered.h).  One launch, grid-stride.
         const uint32_t n_idx = total_tiles * 64u;
-        const int grid = (int)std::min<uint32_t>((uint32_t)sc->blocks_ordered, (n_idx + RT_TRACE_BLOCK - 1) / RT_TRACE_BLOCK);
-        const size_t threads = (size_t)std::max(grid, 1) * RT_TRACE_BLOCK;
+        const int grid = (int)std::min<uint32_t>((uint32_t)sc->blocks_ordered, (n_idx + RT_ORDERED_BLOCK - 1) / RT_ORDERED_BLOCK);
+        const size_t threads = (size_t)std::max(grid, 1) * RT_ORDERED_BLOCK;
         if ((rc = sc->b_mt.ensure(threads * (624 + (size_t)N) * 4))) return rc;
         if ((rc = sc->b_frames.ensure(threads * (size_t)(depth + 1) * OF_COUNT * 4))) return rc;
         OrderedArgs A;
@@ -569,7 +570,7 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         A.tri_shade = sc->ds.tri_shade;
         if (grid > 0) {
             if ((rc = tm.begin(TC_CLOSEST))) return rc;
-            k_pixel_ordered<<<grid, RT_TRACE_BLOCK, 0, st>>>(sc->ds, A, ctl, spill, cand);
+            k_pixel_ordered<<<grid, RT_ORDERED_BLOCK, 0, st>>>(sc->ds, A, ctl, spill, cand);
             if ((rc = tm.end())) return rc;
             HIPCHK(hipGetLastError());
         }
@@ -739,7 +740,7 @@ int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out) {
     sc->blocks_closest = sc->n_cu * std::min(per_cu, cap);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_shadow, RT_TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     sc->blocks_shadow = sc->n_cu * std::min(per_cu, cap);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pixel_ordered, RT_TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pixel_ordered, RT_ORDERED_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     sc->blocks_ordered = sc->n_cu * std::min(per_cu, cap);
     *out = sc;
     return RT_OK;

@@ -283,12 +283,13 @@ struct WaveWork {
 // LDS per wave: RT_STACK_LDS stack entries + RT_LEAF_QUEUE postponed leaves, 8 bytes each per lane.
 #define RT_LDS_ENTRIES (RT_STACK_LDS + RT_LEAF_QUEUE)
 __device__ __forceinline__ TraceStack make_stack(uint2* s_lds, uint32_t* s_cnt, uint2* spill, uint4* cand, const WaveWork& ww) {
+    const uint32_t waves_per_block = blockDim.x / 64;
     TraceStack st;
     st.lds = s_lds + ww.wave * (RT_LDS_ENTRIES * 64);
     st.q = st.lds + RT_STACK_LDS * 64;
     st.cand_cnt = s_cnt + ww.wave * 64;
-    st.cand = cand + ((size_t)blockIdx.x * (RT_TRACE_BLOCK / 64) + ww.wave) * (size_t)(64 * RT_CAND_MAX);
-    size_t wave_slot = (size_t)blockIdx.x * (RT_TRACE_BLOCK / 64) + ww.wave;
+    st.cand = cand + ((size_t)blockIdx.x * waves_per_block + ww.wave) * (size_t)(64 * RT_CAND_MAX);
+    size_t wave_slot = (size_t)blockIdx.x * waves_per_block + ww.wave;
     st.spill = spill + wave_slot * (size_t)((RT_STACK_MAX - RT_STACK_LDS) * 64);
     st.lane = ww.lane;
     st.sp = 0;
@@ -363,7 +364,7 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_closest(
         const unsigned long long clk_end = wall_clock64();
         atomicMax(&ctl->dbg[10], ~clk_start); atomicMax(&ctl->dbg[11], clk_end); atomicAdd(&ctl->dbg[12], clk_end - clk_start); atomicAdd(&ctl->dbg[13], 1ull);
         atomicMax(&ctl->dbg[14], clk_end - clk_start); atomicMax(&ctl->dbg[15], ~(clk_end - clk_start));
-        const uint32_t wg = blockIdx.x * (RT_TRACE_BLOCK / 64) + ww.wave;
+        const uint32_t wg = blockIdx.x * (blockDim.x / 64) + ww.wave;
         if (wg < 8192) {
             unsigned long long* o = g_wave_dbg[wg];
             o[0] = clk_end - clk_start; o[1] = acc.clk_exhausted ? acc.clk_exhausted - clk_start : 0; o[2] = acc.t_sched; o[3] = acc.t_node;
@@ -373,7 +374,7 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_closest(
     }
     {   // step counts live in whichever lane was first active: sum them per wave (after lane 0's plain stores above)
         __threadfence();
-        const uint32_t wg = blockIdx.x * (RT_TRACE_BLOCK / 64) + ww.wave;
+        const uint32_t wg = blockIdx.x * (blockDim.x / 64) + ww.wave;
         if (wg < 8192) {
             unsigned long long* o = g_wave_dbg[wg];
             if (acc.wave_outer) atomicAdd(&o[7], acc.wave_outer);

@@ -124,10 +124,10 @@ struct OrderedArgs {
     const DTriShade* tri_shade;
 };
 
-__global__ void __launch_bounds__(RT_TRACE_BLOCK, 2) k_pixel_ordered(DScene S, OrderedArgs A, Control* ctl, uint2* spill, uint4* cand) {
-    __shared__ uint2 s_lds[(RT_TRACE_BLOCK / 64) * RT_LDS_ENTRIES * 64];
-    __shared__ uint32_t s_cnt[RT_TRACE_BLOCK];
-    __shared__ uint32_t s_cursor[RT_TRACE_BLOCK / 64];
+__global__ void __launch_bounds__(RT_ORDERED_BLOCK, 2) k_pixel_ordered(DScene S, OrderedArgs A, Control* ctl, uint2* spill, uint4* cand) {
+    __shared__ uint2 s_lds[(RT_ORDERED_BLOCK / 64) * RT_LDS_ENTRIES * 64];
+    __shared__ uint32_t s_cnt[RT_ORDERED_BLOCK];
+    __shared__ uint32_t s_cursor[RT_ORDERED_BLOCK / 64];
     WaveWork ww;
     TraceStack st = make_stack(s_lds, s_cnt, spill, cand, ww);
 #ifdef RT_TRACE_STATS

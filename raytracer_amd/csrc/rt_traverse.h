@@ -84,7 +84,10 @@
 #define RT_CAND_MAX 16           // candidate hits a ray can collect from donated subtrees before it falls back to tracing alone
 #endif
 #define RT_STACK_MAX 64          // the reference's stack[64] (raytracer.cpp:533,766)
-#define RT_TRACE_BLOCK 256       // 4 waves per workgroup
+#ifndef RT_TRACE_BLOCK
+#define RT_TRACE_BLOCK 256       // threads per workgroup of the trace kernels
+#endif
+#define RT_ORDERED_BLOCK 256     // rt_ordered.h: 256 VGPRs per lane, 2 waves per SIMD
 
 // Diagnostic build only (-DRT_TRACE_STATS): per-wave step counts to measure SIMD
 // utilisation of the traversal loop.  Never compiled into the shipped library.
