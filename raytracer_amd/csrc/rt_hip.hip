@@ -639,6 +639,8 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         HIPCHK(hipMemcpyAsync(sc->h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (sc->h_ctl->overflow & 8u) return fail(RT_ERR_HIP, "internal: a traced ray reached the wrong lane (rt_ordered.h)");
+        if (sc->h_ctl->overflow & 32u) return fail(RT_ERR_HIP, "internal: a wave exceeded its round bound (rt_traverse.h)");
+        if (sc->h_ctl->overflow & 16u) return fail(RT_ERR_HIP, "internal: a ray waited for its helpers beyond the bound (rt_traverse.h)");
         if (sc->h_ctl->overflow & 4u) return fail(RT_ERR_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
         if (sc->h_ctl->overflow & 3u) return fail(RT_ERR_OVERFLOW, "ray pool overflow");
     }
@@ -670,6 +672,7 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
                 }
             }
         }
+        fprintf(stderr, "[rt stats] board: donor-eligible lane-rounds %llu, gated by idle<=ready %llu, slot busy %llu, claims %llu\n", d[6], d[7], d[8], d[9]);
         fprintf(stderr, "[rt stats] closest timing: waves=%llu kernel span %.1f us, wave lifetime mean %.1f min %.1f max %.1f us\n",
                 d[13], (d[11] - ~d[10]) * 0.01, d[13] ? d[12] * 0.01 / d[13] : 0.0, (~d[15]) * 0.01, d[14] * 0.01);
     }

@@ -280,16 +280,41 @@ struct WaveWork {
     }
 };
 
-// LDS per wave: RT_STACK_LDS stack entries + RT_LEAF_QUEUE postponed leaves, 8 bytes each per lane.
+// LDS of a workgroup that runs the trace loop: per wave RT_STACK_LDS stack entries + RT_LEAF_QUEUE postponed
+// leaves (8 bytes each per lane); per thread the owner-slot words of subtree donation; the task board.
 #define RT_LDS_ENTRIES (RT_STACK_LDS + RT_LEAF_QUEUE)
-__device__ __forceinline__ TraceStack make_stack(uint2* s_lds, uint32_t* s_cnt, uint2* spill, uint4* cand, const WaveWork& ww) {
-    const uint32_t waves_per_block = blockDim.x / 64;
+template <int THREADS>
+struct TraceLds {
+    uint2    stack[(THREADS / 64) * RT_LDS_ENTRIES * 64];
+    uint32_t cand_cnt[THREADS];
+    uint32_t out_cnt[THREADS];
+    uint32_t board[(THREADS / 64) * RT_BOARD_PER_WAVE * 16];
+    uint32_t blk[8];
+    uint32_t cursor[THREADS / 64];       // rt_ordered.h: per-wave item cursor
+    uint8_t  cancel[THREADS];
+};
+template <int THREADS>
+__device__ __forceinline__ TraceStack make_stack(TraceLds<THREADS>& L, uint2* spill, uint4* cand, const WaveWork& ww) {
+    // zero the workgroup-wide words once (all threads of the block call this together at kernel start)
+    for (uint32_t i = threadIdx.x; i < (THREADS / 64) * RT_BOARD_PER_WAVE * 16; i += THREADS) L.board[i] = 0;
+    L.cand_cnt[threadIdx.x] = 0;
+    L.out_cnt[threadIdx.x] = 0;
+    L.cancel[threadIdx.x] = 0;
+    if (threadIdx.x < 8) L.blk[threadIdx.x] = 0;
+    if (threadIdx.x < THREADS / 64) L.cursor[threadIdx.x] = 0;
+    __syncthreads();
     TraceStack st;
-    st.lds = s_lds + ww.wave * (RT_LDS_ENTRIES * 64);
+    st.lds = L.stack + ww.wave * (RT_LDS_ENTRIES * 64);
     st.q = st.lds + RT_STACK_LDS * 64;
-    st.cand_cnt = s_cnt + ww.wave * 64;
-    st.cand = cand + ((size_t)blockIdx.x * waves_per_block + ww.wave) * (size_t)(64 * RT_CAND_MAX);
-    size_t wave_slot = (size_t)blockIdx.x * waves_per_block + ww.wave;
+    st.cand_cnt = L.cand_cnt;
+    st.out_cnt = L.out_cnt;
+    st.cancel = L.cancel;
+    st.board = L.board;
+    st.blk = L.blk;
+    st.n_board = (THREADS / 64) * RT_BOARD_PER_WAVE;
+    st.slot = threadIdx.x;
+    st.cand = cand + (size_t)blockIdx.x * THREADS * RT_CAND_MAX;
+    size_t wave_slot = (size_t)blockIdx.x * (THREADS / 64) + ww.wave;
     st.spill = spill + wave_slot * (size_t)((RT_STACK_MAX - RT_STACK_LDS) * 64);
     st.lane = ww.lane;
     st.sp = 0;
@@ -302,6 +327,41 @@ __device__ __forceinline__ TraceStack make_stack(uint2* s_lds, uint32_t* s_cnt, 
 
 #ifdef RT_TRACE_STATS
 __device__ unsigned long long g_wave_dbg[8192][16];   // per wave of k_trace_closest (diagnostic build)
+#endif
+
+#ifdef RT_TRACE_STATS
+// diagnostic build: totals into ctl->dbg, per-wave breakdown into g_wave_dbg (printed by render_impl)
+__device__ void report_trace_stats(Control* ctl, const TraceStatsAcc& acc, unsigned long long traced, unsigned long long clk_start,
+                                   const TraceStack& st, const WaveWork& ww) {
+    atomicAdd(&ctl->dbg[0], acc.wave_node_steps); atomicAdd(&ctl->dbg[1], acc.lane_node_steps);
+    atomicAdd(&ctl->dbg[2], acc.wave_tri_steps); atomicAdd(&ctl->dbg[3], acc.lane_tri_steps);
+    atomicAdd(&ctl->dbg[4], acc.wave_outer);
+    if (ww.lane == 0) {
+        atomicAdd(&ctl->dbg[5], traced);
+        const unsigned long long clk_end = wall_clock64();
+        atomicMax(&ctl->dbg[10], ~clk_start); atomicMax(&ctl->dbg[11], clk_end); atomicAdd(&ctl->dbg[12], clk_end - clk_start); atomicAdd(&ctl->dbg[13], 1ull);
+        atomicMax(&ctl->dbg[14], clk_end - clk_start); atomicMax(&ctl->dbg[15], ~(clk_end - clk_start));
+        const uint32_t wg = blockIdx.x * (blockDim.x / 64) + ww.wave;
+        if (wg < 8192) {
+            unsigned long long* o = g_wave_dbg[wg];
+            o[0] = clk_end - clk_start; o[1] = acc.clk_exhausted ? acc.clk_exhausted - clk_start : 0; o[2] = acc.t_sched; o[3] = acc.t_node;
+            o[4] = acc.t_tri; o[5] = acc.t_big; o[6] = acc.t_trans; o[7] = 0; o[8] = 0; o[9] = 0;
+            o[10] = acc.n_donations; o[11] = acc.n_coop; o[12] = traced; o[13] = 0; o[14] = 0; o[15] = clk_start;
+        }
+    }
+    atomicAdd(&ctl->dbg[6], acc.n_elig); atomicAdd(&ctl->dbg[7], acc.n_gate); atomicAdd(&ctl->dbg[8], acc.n_casfail); atomicAdd(&ctl->dbg[9], acc.n_claim);
+    if (ww.lane == 0 && blockIdx.x == 0) printf("[board] block 0 wave %u: busy %u ready %u idle %u postcur %u\n", ww.wave, st.blk[0], st.blk[1], st.blk[2], st.blk[3]);
+    {   // step counts live in whichever lane was first active: sum them per wave (after lane 0's plain stores above)
+        __threadfence();
+        const uint32_t wg = blockIdx.x * (blockDim.x / 64) + ww.wave;
+        if (wg < 8192) {
+            unsigned long long* o = g_wave_dbg[wg];
+            if (acc.wave_outer) atomicAdd(&o[7], acc.wave_outer);
+            if (acc.wave_node_steps) { atomicAdd(&o[8], acc.wave_node_steps); atomicAdd(&o[13], acc.lane_node_steps); }
+            if (acc.wave_tri_steps) { atomicAdd(&o[9], acc.wave_tri_steps); atomicAdd(&o[14], acc.lane_tri_steps); }
+        }
+    }
+}
 #endif
 
 // FindClosestHit's search part (raytracer.cpp:405-444) for generation `gen`.
@@ -341,10 +401,9 @@ struct ClosestIO {
 };
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_closest(DScene S, Pool P, Control* ctl, int gen, uint2* spill, uint4* cand) {
-    __shared__ uint2 s_lds[(RT_TRACE_BLOCK / 64) * RT_LDS_ENTRIES * 64];
-    __shared__ uint32_t s_cnt[RT_TRACE_BLOCK];
+    __shared__ TraceLds<RT_TRACE_BLOCK> s_lds;
     WaveWork ww;
-    TraceStack st = make_stack(s_lds, s_cnt, spill, cand, ww);
+    TraceStack st = make_stack(s_lds, spill, cand, ww);
     const uint32_t begin = ctl->gstart[gen], end = ctl->gstart[gen + 1];
 #ifdef RT_TRACE_STATS
     TraceStatsAcc acc = {};
@@ -353,35 +412,12 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_closest(
 #endif
     unsigned long long traced = 0;   // wave-uniform
     ClosestIO io{S, P};
-    trace_persistent<false>(S, io, begin, end, &ctl->cursor_closest, st, traced);
-    if (st.overflow) atomicOr(&ctl->overflow, 4u);
+    trace_persistent<false, true>(S, io, begin, end, &ctl->cursor_closest, st, traced);
+    if (st.overflow) atomicOr(&ctl->overflow, (st.overflow & 48u) | ((st.overflow & ~48u) ? 4u : 0u));
 #ifdef RT_TRACE_STATS
-    atomicAdd(&ctl->dbg[0], acc.wave_node_steps); atomicAdd(&ctl->dbg[1], acc.lane_node_steps);
-    atomicAdd(&ctl->dbg[2], acc.wave_tri_steps); atomicAdd(&ctl->dbg[3], acc.lane_tri_steps);
-    atomicAdd(&ctl->dbg[4], acc.wave_outer);
-    if (ww.lane == 0) {
-        atomicAdd(&ctl->dbg[5], traced);
-        const unsigned long long clk_end = wall_clock64();
-        atomicMax(&ctl->dbg[10], ~clk_start); atomicMax(&ctl->dbg[11], clk_end); atomicAdd(&ctl->dbg[12], clk_end - clk_start); atomicAdd(&ctl->dbg[13], 1ull);
-        atomicMax(&ctl->dbg[14], clk_end - clk_start); atomicMax(&ctl->dbg[15], ~(clk_end - clk_start));
-        const uint32_t wg = blockIdx.x * (blockDim.x / 64) + ww.wave;
-        if (wg < 8192) {
-            unsigned long long* o = g_wave_dbg[wg];
-            o[0] = clk_end - clk_start; o[1] = acc.clk_exhausted ? acc.clk_exhausted - clk_start : 0; o[2] = acc.t_sched; o[3] = acc.t_node;
-            o[4] = acc.t_tri; o[5] = acc.t_big; o[6] = acc.t_trans; o[7] = 0; o[8] = 0; o[9] = 0;
-            o[10] = acc.n_donations; o[11] = acc.n_coop; o[12] = traced; o[13] = 0; o[14] = 0; o[15] = clk_start;
-        }
-    }
-    {   // step counts live in whichever lane was first active: sum them per wave (after lane 0's plain stores above)
-        __threadfence();
-        const uint32_t wg = blockIdx.x * (blockDim.x / 64) + ww.wave;
-        if (wg < 8192) {
-            unsigned long long* o = g_wave_dbg[wg];
-            if (acc.wave_outer) atomicAdd(&o[7], acc.wave_outer);
-            if (acc.wave_node_steps) { atomicAdd(&o[8], acc.wave_node_steps); atomicAdd(&o[13], acc.lane_node_steps); }
-            if (acc.wave_tri_steps) { atomicAdd(&o[9], acc.wave_tri_steps); atomicAdd(&o[14], acc.lane_tri_steps); }
-        }
-    }
+#ifndef RT_STATS_SHADOW
+    report_trace_stats(ctl, acc, traced, clk_start, st, ww);
+#endif
 #endif
     if (traced && ww.lane == 0) atomicAdd(gen == 0 ? &ctl->rays_primary : &ctl->rays_secondary, traced);
 }
@@ -417,19 +453,22 @@ struct ShadowIO {
 };
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_shadow(DScene S, Pool P, Control* ctl, int gen, uint2* spill, uint4* cand) {
-    __shared__ uint2 s_lds[(RT_TRACE_BLOCK / 64) * RT_LDS_ENTRIES * 64];
-    __shared__ uint32_t s_cnt[RT_TRACE_BLOCK];
+    __shared__ TraceLds<RT_TRACE_BLOCK> s_lds;
     WaveWork ww;
-    TraceStack st = make_stack(s_lds, s_cnt, spill, cand, ww);
+    TraceStack st = make_stack(s_lds, spill, cand, ww);
     const uint32_t begin = ctl->sstart[gen], end = ctl->sstart[gen + 1];
 #ifdef RT_TRACE_STATS
-    TraceStatsAcc acc = {};   // the shadow kernel's counts are not reported, but the loop writes through st.acc
+    TraceStatsAcc acc = {};
     st.acc = &acc;
+    const unsigned long long clk_start = wall_clock64();
 #endif
     unsigned long long traced = 0;
     ShadowIO io{S, P};
-    trace_persistent<true>(S, io, begin, end, &ctl->cursor_shadow, st, traced);
-    if (st.overflow) atomicOr(&ctl->overflow, 4u);
+    trace_persistent<true, true>(S, io, begin, end, &ctl->cursor_shadow, st, traced);
+#if defined(RT_TRACE_STATS) && defined(RT_STATS_SHADOW)
+    report_trace_stats(ctl, acc, traced, clk_start, st, ww);
+#endif
+    if (st.overflow) atomicOr(&ctl->overflow, (st.overflow & 48u) | ((st.overflow & ~48u) ? 4u : 0u));
     if (traced && ww.lane == 0) atomicAdd(&ctl->rays_shadow, traced);
 }
 

@@ -125,11 +125,10 @@ struct OrderedArgs {
 };
 
 __global__ void __launch_bounds__(RT_ORDERED_BLOCK, 2) k_pixel_ordered(DScene S, OrderedArgs A, Control* ctl, uint2* spill, uint4* cand) {
-    __shared__ uint2 s_lds[(RT_ORDERED_BLOCK / 64) * RT_LDS_ENTRIES * 64];
-    __shared__ uint32_t s_cnt[RT_ORDERED_BLOCK];
-    __shared__ uint32_t s_cursor[RT_ORDERED_BLOCK / 64];
+    __shared__ TraceLds<RT_ORDERED_BLOCK> s_lds;
+    uint32_t* s_cursor = s_lds.cursor;
     WaveWork ww;
-    TraceStack st = make_stack(s_lds, s_cnt, spill, cand, ww);
+    TraceStack st = make_stack(s_lds, spill, cand, ww);
 #ifdef RT_TRACE_STATS
     TraceStatsAcc acc = {};
     st.acc = &acc;
@@ -432,19 +431,19 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, 2) k_pixel_ordered(DScene S,
                 if (ww.lane == 0) s_cursor[ww.wave] = 0;
                 LaneClosestIO io{S, L, ww.lane};
                 unsigned long long traced = 0;
-                trace_persistent<false>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
+                trace_persistent<false, false>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
             }
             if (__any(L.req == OREQ_ANYHIT)) {
                 if (ww.lane == 0) s_cursor[ww.wave] = 0;
                 LaneShadowIO io{S, L, ww.lane};
                 unsigned long long traced = 0;
-                trace_persistent<true>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
+                trace_persistent<true, false>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
             }
         }
     }
 #undef OFR
 #undef OFR_U
-    if (st.overflow) atomicOr(&ctl->overflow, 4u);
+    if (st.overflow) atomicOr(&ctl->overflow, (st.overflow & 48u) | ((st.overflow & ~48u) ? 4u : 0u));
     if (L.bad_item) atomicOr(&ctl->overflow, 8u);
     if (n_primary) atomicAdd(&ctl->rays_primary, n_primary);
     if (n_secondary) atomicAdd(&ctl->rays_secondary, n_secondary);

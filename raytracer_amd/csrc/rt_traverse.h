@@ -48,7 +48,7 @@
 #include "rt_device.h"
 
 #ifndef RT_STACK_LDS
-#define RT_STACK_LDS 11          // entries per lane kept in LDS
+#define RT_STACK_LDS 10          // entries per lane kept in LDS
 #endif
 #ifndef RT_LEAF_QUEUE
 #define RT_LEAF_QUEUE 8          // mesh leaves a lane may postpone before the wave switches to triangle tests
@@ -72,7 +72,7 @@
 #define RT_REFILL_MIN_ANY 32
 #endif
 #ifndef RT_DONATE_PASSES
-#define RT_DONATE_PASSES 4       // stack entries a busy lane may give away per round (helpers included, so a subtree fans out)
+#define RT_DONATE_PASSES 16      // stack entries a busy lane may post per round (helpers included, so a subtree fans out)
 #endif
 #ifndef RT_REFILL_PATIENCE
 #define RT_REFILL_PATIENCE 2     // rounds a wave waits for RT_REFILL_MIN idle lanes before it refills the ones it has
@@ -85,16 +85,24 @@
 #endif
 #define RT_STACK_MAX 64          // the reference's stack[64] (raytracer.cpp:533,766)
 #ifndef RT_TRACE_BLOCK
-#define RT_TRACE_BLOCK 256       // threads per workgroup of the trace kernels
+#define RT_TRACE_BLOCK 1024      // threads per workgroup of the trace kernels: one workgroup per CU, its 16 waves share the task board
 #endif
 #define RT_ORDERED_BLOCK 256     // rt_ordered.h: 256 VGPRs per lane, 2 waves per SIMD
+#define RT_BOARD_PER_WAVE 4      // task-board slots per wave of a workgroup (16 words each)
+#ifndef RT_ROUND_CAP
+#define RT_ROUND_CAP (1u << 26)   // rounds of one wave in one kernel; a healthy frame needs tens
+#endif
+#define RT_WAIT_ROUNDS_MAX 4000000u   // an owner never waits longer for its helpers (error 16 instead of a hang)
+#ifndef RT_LINGER_SPINS
+#define RT_LINGER_SPINS 20000    // rounds a finished wave keeps looking at the board while others of its workgroup work
+#endif
 
 // Diagnostic build only (-DRT_TRACE_STATS): per-wave step counts to measure SIMD
 // utilisation of the traversal loop.  Never compiled into the shipped library.
 #ifdef RT_TRACE_STATS
 struct TraceStatsAcc {
     unsigned long long wave_node_steps, lane_node_steps, wave_tri_steps, lane_tri_steps, wave_outer, lane_rays, wave_batches, wave_pops, lane_pops;
-    unsigned long long t_sched, t_node, t_tri, t_big, t_trans, clk_exhausted, n_donations, n_coop, n_replays;
+    unsigned long long t_sched, t_node, t_tri, t_big, t_trans, clk_exhausted, n_donations, n_coop, n_replays, n_elig, n_gate, n_casfail, n_claim, n_culled;
 };
 #define RT_CLK(v) const unsigned long long v = wall_clock64()
 #define RT_STAT(x) x
@@ -110,8 +118,15 @@ struct TraceStack {
     uint2*    lds;        // [RT_STACK_LDS][64] for this wave: (link, bits of tEnter)
     uint2*    spill;      // [(RT_STACK_MAX-RT_STACK_LDS)][64] for this wave (global)
     uint2*    q;          // [RT_LEAF_QUEUE][64] postponed mesh leaves, in visiting order: (link, bits of tEnter)
-    uint32_t* cand_cnt;   // [64] (LDS) candidates collected for the ray owned by lane k
-    uint4*    cand;       // [64][RT_CAND_MAX] (global) for this wave: (triangle slot, t bits, leaf tEnter bits, -)
+    // workgroup-wide (LDS unless noted), indexed by the owner's slot = wave * 64 + lane:
+    uint32_t* cand_cnt;   // [threads] candidates collected for the ray of that slot
+    uint32_t* out_cnt;    // [threads] subtrees of that ray that other lanes still trace
+    uint8_t*  cancel;     // [threads] any-hit found for that ray by a helper
+    uint4*    cand;       // [threads][RT_CAND_MAX] (global): (triangle slot, t bits, leaf tEnter bits, -)
+    uint32_t* board;      // [n_board][16] task board: state, home, link, tEnter, bound, ray (9), object, kind
+    uint32_t* blk;        // [8] busy waves, ready tasks, idle lanes, post cursor, cursor drained
+    uint32_t  n_board;
+    uint32_t  slot;       // this lane's slot in the workgroup
     uint32_t  lane;
     uint32_t  sp;
     uint32_t  overflow;
@@ -338,7 +353,7 @@ __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int src) { return (ui
 //   result itself and returns 1 (a ray that needs no traversal) or 0 (no ray);
 //   IO::store(item, verdict, out, minT) stores the result of a traversed ray
 //   (verdict = has / in-shadow).
-template <bool ANYHIT, class IO>
+template <bool ANYHIT, bool LINGER, class IO>
 __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32_t end, uint32_t* cursor, TraceStack& st,
                                  unsigned long long& traced) {
     constexpr uint32_t QCAP = ANYHIT ? RT_LEAF_QUEUE_ANY : RT_LEAF_QUEUE;
@@ -352,7 +367,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
     // ---- per-lane slot: a ray this lane owns, or a donated subtree of lane `home`'s ray
     bool alive = false;          // traversing (owner or helper)
     bool helper = false;
-    uint32_t home = lane;
+    uint32_t home = st.slot;     // workgroup slot (wave * 64 + lane) of the ray's owner
     uint32_t item = 0;
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, 0);
     float time = 0.f, minT = 0.f;
@@ -375,9 +390,11 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
     uint32_t don_next = 0;       // stack slot of the bottom-most mesh-level entry not yet given away
     bool donated = false;        // owner: subtrees of the mesh traversal in flight were given away
     bool no_donate = false;      // owner: re-traversing alone after a candidate overflow
-    bool cancel_req = false;     // any-hit found for ray `home`: everybody working on it stops
-    bool help_active = false;    // owner: a helper is still working for this lane
     bool exhausted = false;      // wave-uniform: the cursor has passed the last item
+    bool was_busy = false;       // wave-uniform: this wave is counted in st.blk[0]
+    uint32_t idle_posted = 0;    // wave-uniform: idle lanes this wave has announced in st.blk[2]
+    uint32_t spins = 0, round = 0;
+    uint32_t wait_rounds = 0;    // owner: rounds spent waiting for helpers (bounded, see RT_WAIT_ROUNDS_MAX)
     // Order in which the cursor hands out the items.  Items come in blocks of 64 neighbours (one 8x8 pixel
     // tile for primary rays).  Expensive rays cluster (silhouettes): a wave that takes a whole expensive
     // block is busy three times longer than the average wave and the kernel waits for it.  So the cursor
@@ -390,26 +407,11 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
 
     for (;;) {
         RT_CLK(c0);
-        // ---- an any-hit verdict reached for a split ray ends the ray and all its helpers (wave-uniform control flow)
-        if (ANYHIT) {
-            uint64_t cm = __ballot(cancel_req);
-            if (cm != 0) {
-                uint64_t cancel_homes = 0;
-                while (cm != 0) {
-                    const int src = __ffsll((long long)cm) - 1;
-                    cm &= cm - 1;
-                    cancel_homes |= 1ull << lane_bcast(home, src);
-                }
-                cancel_req = false;
-                if (alive && ((cancel_homes >> home) & 1ull)) {
-                    if (!helper) io.store(item, true, out, minT);
-                    alive = false; helper = false; in_mesh = false; donated = false; no_donate = false;
-                    cur = RT_LINK_DONE; st.sp = 0; home = lane;
-                }
-            }
-        }
-
         // ---- refill idle lanes
+        if (!exhausted && st.blk[4] != 0) {          // another wave of the workgroup has seen the cursor drained
+            exhausted = true;
+            RT_STAT(st.acc->clk_exhausted = wall_clock64();)
+        }
         if (!exhausted) {
             const uint64_t idle = __ballot(!alive);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -422,7 +424,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(cursor, n_idle);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (base + n_idle >= n_padded) { exhausted = true; RT_STAT(st.acc->clk_exhausted = wall_clock64();) }
+                if (base + n_idle >= n_padded) { exhausted = true; if (LINGER && lane == 0) st.blk[4] = 1u; RT_STAT(st.acc->clk_exhausted = wall_clock64();) }
                 int got = 0;
                 if (!alive) {
                     // cursor value -> item: strip-interleaved over the 64-item blocks (see above)
@@ -438,7 +440,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 if (got == 2) {
                     alive = true;
                     helper = false;
-                    home = lane;
+                    home = st.slot;
                     st.sp = 0;
                     in_mesh = false;
                     donated = false;
@@ -457,76 +459,123 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 }
             }
         }
-        if (!__any(alive)) {
-            if (exhausted) break;
-            continue;
-        }
-
-        // ---- subtree donation to idle lanes
+        // ---- subtree donation over the workgroup's task board (see the header)
 #ifdef RT_SPLIT_ALWAYS
         const bool split_now = S.donate_ok != 0;     // test build: exercise the donation path all the time
 #else
         const bool split_now = exhausted && S.donate_ok != 0;
 #endif
+        round++;
+        if (round > RT_ROUND_CAP) {                 // never spin forever on the GPU: report instead (error 32)
+            st.overflow |= 32u;
+            RT_STAT(if (lane == 0) printf("[stuck] block %d wave slot %u: alive %llx helper %llx inmesh %llx donated %llx cur0 %x busy %u ready %u idle %u out[me] %u\n", (int)blockIdx.x, st.slot, (unsigned long long)__ballot(alive), (unsigned long long)__ballot(helper), (unsigned long long)__ballot(in_mesh), (unsigned long long)__ballot(donated), cur, st.blk[0], st.blk[1], st.blk[2], st.out_cnt[st.slot]);)
+            break;
+        }
         if (split_now) {
-            uint64_t idle = __ballot(!alive);
-            for (int pass = 0; pass < RT_DONATE_PASSES && idle != 0; pass++) {
-            uint64_t donors = __ballot(alive && in_mesh && !no_donate && don_next < st.sp);
-            if (donors == 0) break;
-            while (idle != 0 && donors != 0) {
-                const int d = __ffsll((long long)donors) - 1;
-                donors &= donors - 1;                      // one entry per donor per round
-                uint32_t dl = RT_LINK_NONE;
-                float dt = 0.f;
-                if ((int)lane == d) {
+            // (a) an idle lane takes a posted subtree
+            if (!alive && st.blk[1] != 0) {
+                const uint32_t start = (lane * 7u + st.slot + round) % st.n_board;
+                for (uint32_t k = 0; k < 4u && !alive; k++) {
+                    uint32_t* rec = st.board + ((start + k) % st.n_board) * 16u;
+                    // (rec[15]: closest-hit or any-hit subtree — in rt_ordered.h the waves of a workgroup run both kinds of loop)
+                    if (rec[0] == 2u && rec[15] == (ANYHIT ? 1u : 0u) && atomicCAS(&rec[0], 2u, 3u) == 2u) {
+                        home = rec[1];
+                        cur = rec[2];
+                        cur_t = __uint_as_float(rec[3]);
+                        tmax = __uint_as_float(rec[4]);
+                        ar.ox = __uint_as_float(rec[5]); ar.oy = __uint_as_float(rec[6]); ar.oz = __uint_as_float(rec[7]);
+                        ar.dx = __uint_as_float(rec[8]); ar.dy = __uint_as_float(rec[9]); ar.dz = __uint_as_float(rec[10]);
+                        ar.ix = __uint_as_float(rec[11]); ar.iy = __uint_as_float(rec[12]); ar.iz = __uint_as_float(rec[13]);
+                        cur_obj = rec[14];
+                        rec[0] = 0u;                         // slot free again
+                        atomicSub(&st.blk[1], 1u);
+                        RT_STAT(st.acc->n_claim++;)
+                        alive = true;
+                        helper = true;
+                        in_mesh = true;
+                        mesh_found = false;
+                        donated = false;
+                        no_donate = false;
+                        qn = 0;
+                        st.sp = 0;
+                        st.push(RT_LINK_SENTINEL, -1.0f);
+                        don_next = st.sp;
+                    }
+                }
+            }
+            // (b) the wave tells the workgroup how many of its lanes are idle
+            {
+                const uint32_t n_idle_now = (uint32_t)__popcll(__ballot(!alive));
+                if (n_idle_now != idle_posted) {
+                    if (lane == 0) atomicAdd(&st.blk[2], n_idle_now - idle_posted);   // unsigned wrap = signed difference
+                    idle_posted = n_idle_now;
+                }
+            }
+            // (c) a busy lane posts the bottom-most entry of its mesh-level stack while idle lanes outnumber posted tasks
+            RT_STAT(if (alive && in_mesh && !no_donate && don_next < st.sp) { st.acc->n_elig++; if (!(st.blk[2] > st.blk[1])) st.acc->n_gate++; })
+            for (int pass = 0; pass < RT_DONATE_PASSES && alive && in_mesh && !no_donate && don_next < st.sp && st.blk[2] > st.blk[1]; pass++) {
+                uint32_t* rec = st.board + (atomicAdd(&st.blk[3], 1u) % st.n_board) * 16u;
+                const bool got_slot = atomicCAS(&rec[0], 0u, 1u) == 0u;
+                RT_STAT(if (!got_slot) st.acc->n_casfail++;)
+                if (got_slot) {
                     const uint2 e = st.read_at(don_next);
                     st.write_at(don_next, make_uint2(RT_LINK_NONE, 0u));
                     don_next++;
-                    dl = e.x;
-                    dt = __uint_as_float(e.y);
-                    if (dl != RT_LINK_NONE && ((tmax < dt) || (dt == 0.0f && tmax <= 0.0f))) dl = RT_LINK_NONE;   // culled by now
+                    const float dt = __uint_as_float(e.y);
+                    if (e.x != RT_LINK_NONE && !((tmax < dt) || (dt == 0.0f && tmax <= 0.0f))) {
+                        if (!helper && !donated) {           // first subtree of this mesh traversal that leaves the owner
+                            donated = true;
+                            st.cand_cnt[st.slot] = 0;
+                            st.cancel[st.slot] = 0;
+                        }
+                        atomicAdd(&st.out_cnt[home], 1u);
+                        rec[1] = home; rec[2] = e.x; rec[3] = e.y; rec[4] = __float_as_uint(tmax);
+                        rec[5] = __float_as_uint(ar.ox); rec[6] = __float_as_uint(ar.oy); rec[7] = __float_as_uint(ar.oz);
+                        rec[8] = __float_as_uint(ar.dx); rec[9] = __float_as_uint(ar.dy); rec[10] = __float_as_uint(ar.dz);
+                        rec[11] = __float_as_uint(ar.ix); rec[12] = __float_as_uint(ar.iy); rec[13] = __float_as_uint(ar.iz);
+                        rec[14] = cur_obj;
+                        rec[15] = ANYHIT ? 1u : 0u;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        rec[0] = 2u;                         // ready
+                        atomicAdd(&st.blk[1], 1u);
+                        RT_STAT(st.acc->n_donations++;)
+                    } else {
+                        rec[0] = 0u;                         // the entry is culled by now: nothing to give
+                    }
                 }
-                dl = lane_bcast(dl, d);
-                if (dl == RT_LINK_NONE) continue;
-                RT_STAT(st.acc->n_donations++;)
-                const int h = __ffsll((long long)idle) - 1;
-                idle &= idle - 1;
-                const uint32_t d_home = lane_bcast(home, d), d_obj = lane_bcast(cur_obj, d);
-                const float b_t = lane_bcast(dt, d), b_tmax = lane_bcast(tmax, d);
-                const float b_ox = lane_bcast(ar.ox, d), b_oy = lane_bcast(ar.oy, d), b_oz = lane_bcast(ar.oz, d);
-                const float b_dx = lane_bcast(ar.dx, d), b_dy = lane_bcast(ar.dy, d), b_dz = lane_bcast(ar.dz, d);
-                const float b_ix = lane_bcast(ar.ix, d), b_iy = lane_bcast(ar.iy, d), b_iz = lane_bcast(ar.iz, d);
-                if ((int)lane == d && !helper && !donated) {
-                    donated = true;
-                    st.cand_cnt[lane] = 0;
-                }
-                if ((int)lane == h) {
-                    alive = true;
-                    helper = true;
-                    home = d_home;
-                    cur_obj = d_obj;
-                    ar.ox = b_ox; ar.oy = b_oy; ar.oz = b_oz; ar.dx = b_dx; ar.dy = b_dy; ar.dz = b_dz;
-                    ar.ix = b_ix; ar.iy = b_iy; ar.iz = b_iz;
-                    tmax = b_tmax;
-                    in_mesh = true;
-                    mesh_found = false;
+            }
+            // (d) any-hit found by somebody working on the same ray: helpers drop their subtree, the owner stops
+            //     its own part (pops down to the sentinel) and finishes once its helpers are gone
+            if (ANYHIT && alive && (helper || donated) && st.cancel[home] != 0) {
+                if (helper) {
+                    atomicSub(&st.out_cnt[home], 1u);
+                    alive = false; helper = false; in_mesh = false; cur = RT_LINK_DONE; st.sp = 0; qn = 0;
+                } else if (cur != RT_LINK_SENTINEL) {
                     qn = 0;
-                    st.sp = 0;
-                    st.push(RT_LINK_SENTINEL, -1.0f);
-                    don_next = st.sp;
-                    cur = dl;
-                    cur_t = b_t;
+                    cur = st.pop(-1.0f, cur_t);              // everything above the sentinel is culled by a negative bound
                 }
             }
+        }
+
+        // ---- nothing to do in this wave: leave, or stay to help the workgroup
+        if (!__any(alive)) {
+            if (!exhausted) continue;
+            if (was_busy) {
+                was_busy = false;
+                if (lane == 0) atomicSub(&st.blk[0], 1u);
             }
-            // which owners still have helpers at work
-            uint64_t hm = __ballot(alive && helper), active_homes = 0;
-            while (hm != 0) {
-                const int src = __ffsll((long long)hm) - 1;
-                hm &= hm - 1;
-                active_homes |= 1ull << lane_bcast(home, src);
+            // A finished wave of a trace kernel stays while other waves of its workgroup work: they may post
+            // subtrees.  Leaving early is always safe (a poster takes its own tasks back when its lanes go idle).
+            if (!LINGER || !split_now || st.blk[0] == 0 || (++spins > RT_LINGER_SPINS && st.blk[1] == 0)) {
+                if (idle_posted != 0 && lane == 0) atomicSub(&st.blk[2], idle_posted);
+                break;
             }
-            help_active = ((active_homes >> lane) & 1ull) != 0;
+            __builtin_amdgcn_s_sleep(32);
+            continue;
+        }
+        if (!was_busy) {
+            was_busy = true;
+            if (lane == 0) atomicAdd(&st.blk[0], 1u);
         }
 
         // ---- node phase: collapsed interior records of either level; mesh leaves are queued
@@ -584,8 +633,14 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         // Returns true when the lane is finished with its ray / subtree (any-hit).
         auto accept = [&](uint32_t ti, float t, float bb, float gg, float te) -> bool {
             if (helper) {
-                const uint32_t slot = atomicAdd(&st.cand_cnt[home], 1u);
-                if (slot < RT_CAND_MAX) st.cand[home * RT_CAND_MAX + slot] = make_uint4(ti, __float_as_uint(t), __float_as_uint(te), 0u);
+                const uint32_t k = atomicAdd(&st.cand_cnt[home], 1u);
+                if (k < RT_CAND_MAX) {
+                    // read by the owner, possibly in another wave: written through to L2 (agent scope), read past L1
+                    uint32_t* cp = reinterpret_cast<uint32_t*>(&st.cand[home * RT_CAND_MAX + k]);
+                    __hip_atomic_store(cp, ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cp + 1, __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cp + 2, __float_as_uint(te), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 if (t >= te) tmax = t;
             } else {
                 tmax = t;
@@ -598,7 +653,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 // Untransformed mesh: worldT == t < testMinT == minT, so the
                 // reference's verdict is already known.
                 if (!(S.objects[cur_obj].flags & RT_OBJ_HAS_TRANSFORM)) {
-                    if (helper || donated) cancel_req = true;
+                    if (helper || donated) st.cancel[home] = 1;
                     return true;
                 }
             }
@@ -697,6 +752,14 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             if (big && !fin) cur = st.pop(tmax, cur_t);
         }
 
+        // An owner that found its any-hit while helpers still trace parts of the same ray has told them
+        // (st.cancel); it drops the rest of its own part and waits at the sentinel until they are gone, so
+        // that no helper of this ray is left when the slot takes its next ray.
+        if (ANYHIT && fin && !helper && donated) {
+            fin = false;
+            if (cur != RT_LINK_SENTINEL) cur = st.pop(-1.0f, cur_t);   // (the sentinel may already have been popped)
+        }
+
         // ---- per-lane transitions between the levels
         RT_CLK(c4);
         bool finished = fin;
@@ -710,9 +773,18 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 if (helper) { finished = true; break; }        // the donated subtree is done
                 bool redo = false;
                 if (donated) {
-                    if (help_active) break;                    // wait for the helpers (cur stays on the sentinel)
+                    if (st.out_cnt[st.slot] != 0) {            // wait for the helpers (cur stays on the sentinel)
+                        if (++wait_rounds > RT_WAIT_ROUNDS_MAX) { st.overflow |= 16u; } else break;
+                    }
+                    wait_rounds = 0;
+                    if (ANYHIT && st.cancel[st.slot] != 0) {   // somebody found the any-hit (untransformed mesh)
+                        donated = false;
+                        fin = true;
+                        finished = true;
+                        break;
+                    }
                     // ---- replay the helpers' candidates in visiting order with the reference's rule
-                    const uint32_t nc = st.cand_cnt[lane];
+                    const uint32_t nc = st.cand_cnt[st.slot];
                     if (nc > RT_CAND_MAX) {
                         redo = true;                           // too many to keep: trace this mesh again, alone
                     } else {
@@ -721,8 +793,8 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                         for (uint32_t r = 0; r < nc; r++) {
                             uint4 best = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
                             for (uint32_t k = 0; k < nc; k++) {
-                                // written by other lanes of this wave: read past the (non-coherent) vector L1
-                                const uint32_t* cp = reinterpret_cast<const uint32_t*>(&st.cand[lane * RT_CAND_MAX + k]);
+                                // written by other lanes of the workgroup: read past the (non-coherent) vector L1
+                                const uint32_t* cp = reinterpret_cast<const uint32_t*>(&st.cand[st.slot * RT_CAND_MAX + k]);
                                 uint4 c;
                                 c.x = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 c.y = __hip_atomic_load(cp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -842,9 +914,16 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         } while (0);
 
         if (alive && finished) {
-            if (!helper) io.store(item, ANYHIT ? fin : has, out, minT);
+            if (helper) {
+                // the recorded candidates have reached L2 (the owner, in this workgroup, reads them past L1) before the count drops
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                atomicSub(&st.out_cnt[home], 1u);
+            } else {
+                io.store(item, ANYHIT ? fin : has, out, minT);
+            }
             alive = false;
-            helper = false;        // `home` stays: a pending cancel_req names it
+            helper = false;
             in_mesh = false;
             donated = false;
             no_donate = false;

@@ -15,6 +15,8 @@ for spec in sys.argv[2:]:
         hs = util.golden_scene(a[0])
     elif kind == "mesh":
         hs = scenes.mesh_scene(int(a[0]), int(a[1]), int(a[2])).build()
+    elif kind == "glossy":
+        hs = scenes.glossy_area_scene(int(a[0]), int(a[1]), int(a[2]), int(a[3])).build()
     else:
         hs = scenes.instanced_scene(int(a[0]), int(a[1]), int(a[2])).build()
     ds = DeviceScene(hs, 0)
