@@ -593,35 +593,29 @@ __device__ __forceinline__ V3 hit_normal(const DScene& S, uint32_t kind_index, u
     return normal;
 }
 
-// Wave-aggregated allocation: every lane asks for `n` (0..2) consecutive slots.
-__device__ __forceinline__ uint32_t wave_alloc(uint32_t* counter, uint32_t n) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const unsigned long long m1 = __ballot(n >= 1), m2 = __ballot(n >= 2);
-    const uint32_t total = __popcll(m1) + __popcll(m2);
-    uint32_t base = 0;
-    if (total) {
-        if (lane == 0) base = atomicAdd(counter, total);
-        base = __builtin_amdgcn_readfirstlane(base);
-    }
-    return base + __popcll(m1 & lt) + __popcll(m2 & lt);
-}
-// same for an arbitrary per-lane count (shadow slots: n_point_lights per lit record)
-__device__ __forceinline__ uint32_t wave_alloc_n(uint32_t* counter, uint32_t n) {
-    const uint32_t lane = threadIdx.x & 63u;
+// Block-aggregated allocation of consecutive slots: every thread asks for `n`; one atomic per 256-thread block
+// (same-address atomics from every wave cost ~5 ns each in sequence — with one per wave they, not the memory
+// traffic, set k_shade's time).  Slots stay in thread order inside the block.  All threads of the block call it.
+__device__ __forceinline__ uint32_t block_alloc(uint32_t* counter, uint32_t n, uint32_t* s_tmp /* [8] LDS */) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t incl = n;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         uint32_t v = __shfl_up(incl, off, 64);
         if ((int)lane >= off) incl += v;
     }
-    const uint32_t total = __shfl(incl, 63, 64);
-    uint32_t base = 0;
-    if (total) {
-        if (lane == 0) base = atomicAdd(counter, total);
-        base = __builtin_amdgcn_readfirstlane(base);
+    if (lane == 63) s_tmp[wave] = incl;            // wave totals
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t0 = s_tmp[0], t1 = s_tmp[1], t2 = s_tmp[2], t3 = s_tmp[3];
+        const uint32_t total = t0 + t1 + t2 + t3;
+        const uint32_t base = total ? atomicAdd(counter, total) : 0u;
+        s_tmp[4] = base; s_tmp[5] = base + t0; s_tmp[6] = base + t0 + t1; s_tmp[7] = base + t0 + t1 + t2;
     }
-    return base + incl - n;
+    __syncthreads();
+    const uint32_t r = s_tmp[4 + wave] + incl - n;
+    __syncthreads();                               // s_tmp is reused by the next call
+    return r;
 }
 
 // After the closest-hit search of generation `gen`: finish FindClosestHit
@@ -630,6 +624,7 @@ __device__ __forceinline__ uint32_t wave_alloc_n(uint32_t* counter, uint32_t n) 
 // and append them to the pools.  This is the ray-compaction step: only live
 // continuations get a slot (ballot/popcount prefix, one atomic per wave).
 __global__ void __launch_bounds__(256) k_shade(DScene S, Pool P, Control* ctl, int gen) {
+    __shared__ uint32_t s_tmp[8];
     const uint32_t begin = ctl->gstart[gen], end = ctl->gstart[gen + 1];
     const uint32_t span = end - begin;
     const uint32_t rounds = (span + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
@@ -668,8 +663,8 @@ __global__ void __launch_bounds__(256) k_shade(DScene S, Pool P, Control* ctl, i
                 }
             }
         }
-        uint32_t child = wave_alloc(&ctl->n_records, n_child);
-        uint32_t sbase = wave_alloc_n(&ctl->n_shadow, n_shadow);
+        uint32_t child = block_alloc(&ctl->n_records, n_child, s_tmp);
+        uint32_t sbase = block_alloc(&ctl->n_shadow, n_shadow, s_tmp);
         if (!valid) continue;
         uint32_t c0 = RT_NO_CHILD, c1 = RT_NO_CHILD;
         if (n_child) {
