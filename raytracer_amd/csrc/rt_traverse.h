@@ -68,8 +68,21 @@
 #ifndef RT_STRIP_ANY
 #define RT_STRIP_ANY 64          // any-hit: shadow slots of one record are neighbours and differ in direction; keep blocks whole
 #endif
+// node phase exit: at most EXIT_FEW lanes still walking and at least EXIT_WAIT lanes waiting with queued leaves
+#ifndef RT_EXIT_FEW
+#define RT_EXIT_FEW 24
+#endif
+#ifndef RT_EXIT_WAIT
+#define RT_EXIT_WAIT 8
+#endif
+#ifndef RT_EXIT_FEW_ANY
+#define RT_EXIT_FEW_ANY 20
+#endif
+#ifndef RT_EXIT_WAIT_ANY
+#define RT_EXIT_WAIT_ANY 1
+#endif
 #ifndef RT_REFILL_MIN_ANY
-#define RT_REFILL_MIN_ANY 32
+#define RT_REFILL_MIN_ANY 48
 #endif
 #ifndef RT_DONATE_PASSES
 #define RT_DONATE_PASSES 16      // stack entries a busy lane may post per round (helpers included, so a subtree fans out)
@@ -359,6 +372,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
     constexpr uint32_t QCAP = ANYHIT ? RT_LEAF_QUEUE_ANY : RT_LEAF_QUEUE;
     constexpr uint32_t STRIP = ANYHIT ? RT_STRIP_ANY : RT_STRIP;
     constexpr uint32_t REFILL_MIN = ANYHIT ? RT_REFILL_MIN_ANY : RT_REFILL_MIN;
+    constexpr uint32_t EXIT_FEW = ANYHIT ? RT_EXIT_FEW_ANY : RT_EXIT_FEW, EXIT_WAIT = ANYHIT ? RT_EXIT_WAIT_ANY : RT_EXIT_WAIT;
     static_assert(64 % STRIP == 0, "strips tile a 64-item block");
     static_assert(RT_LEAF_QUEUE_ANY <= RT_LEAF_QUEUE, "the LDS queue is sized by RT_LEAF_QUEUE");
     const uint32_t lane = st.lane;
@@ -588,7 +602,13 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             // (wave-uniform exit: the two phases must not be interleaved by the compiler).
             const bool leaf_here = (cur & RT_LINK_LEAF) != 0;
             const bool want = !leaf_here || (in_mesh && cur < 0xFC000000u && qn < QCAP);
-            if (!__any(want)) break;
+            {   // Leave the node phase also when only a few lanes still walk while others wait with queued
+                // leaves: the walkers keep their place and go on in the next node phase.  (A wave completes a
+                // step about every 1.3 us whatever the number of active lanes, so steps with few lanes cost
+                // as much as full ones.)
+                const uint32_t n_want = (uint32_t)__popcll(__ballot(want)), n_wait = (uint32_t)__popcll(__ballot(!want && qn != 0));
+                if (n_want == 0 || (n_want <= EXIT_FEW && n_wait >= EXIT_WAIT)) break;
+            }
             if (want) {
                 if (leaf_here) {
                     st.q[qn * 64 + st.lane] = make_uint2(cur, __float_as_uint(cur_t));
@@ -764,6 +784,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         RT_CLK(c4);
         bool finished = fin;
         if (alive && !fin) do {
+            if (!(cur & RT_LINK_LEAF)) break;          // still on an interior record (the node phase was left early)
             if (in_mesh) {
                 if (cur != RT_LINK_SENTINEL) {
                     // a mesh leaf is waiting (queue was full): it was accepted with an older minT, re-check it
