@@ -44,6 +44,14 @@
 //     box-test instructions instead of serialising nested loops.
 //   * 1/dir is computed once per active ray (the reference recomputes the same
 //     quotient at every box, raytracer.cpp:822,842,862).
+//   * scheduling (trace_persistent below): ray slots refilled from a strip-interleaved
+//     cursor, subtrees handed to idle lanes of the workgroup over an LDS task board with
+//     an exact replay of their candidate hits, big leaves tested by the whole wave.
+//     None of it changes which leaves are tested against which minT, in which order.
+// Non-finite geometry is out of contract: a NaN `t` is accepted by the reference's
+// comparisons (raytracer.cpp:941) and would then win every later comparison; the
+// whole-wave leaf test and the candidate replay order hits by `t` and would not
+// reproduce that.
 #pragma once
 #include "rt_device.h"
 
@@ -341,25 +349,32 @@ __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int src) { return (ui
 //    generation's cursor (one atomic) and hands them to the idle lanes.  So a wave is
 //    not bound to the slowest ray of a fixed 64-ray batch, while refilling in runs
 //    keeps neighbouring pixels together.
-//  * Subtree donation: once the cursor is exhausted, idle lanes take over the
-//    bottom-most entry of a busy lane's mesh-level stack (the subtree the busy lane
-//    would reach LAST).  The OWNER of the ray keeps the reference's exact sequential
-//    state for the part it traverses itself, which precedes every donated subtree in
-//    visiting order.  A HELPER traverses its subtree with a bound b that starts at the
-//    donor's bound and RECORDS every triangle it would accept, (triangle, t, tEnter of
-//    its leaf), lowering b only when t >= tEnter.  b is then never below the minT the
-//    reference has at the same point (by induction over the visiting order: the
-//    reference either accepts the same triangle, or rejects it because minT <= t, or
-//    culls the leaf because minT < tEnter <= t), so every triangle the reference
-//    accepts inside the subtree is among the recorded ones (box and triangle tests
-//    are monotone in the bound).  When the owner's own part and all helpers are done,
-//    the owner replays the candidates in visiting order (= ascending triangle slot:
-//    the builder partitions the primitive array in place, raytracer.cpp:247-262, and
-//    the left child is visited first) with the reference's rule: skip if minT culls
-//    the leaf box, accept if t < minT.  That is the reference's result exactly; what
-//    changes is that one long ray is traced by many lanes (the slowest ray of the
-//    1M-triangle frame takes ~1000 sequential steps, longer than the rest of the
-//    kernel).  A ray with more than RT_CAND_MAX candidates re-traverses the mesh alone.
+//  * Subtree donation: once the cursor is drained (a wave that sees it tells its
+//    workgroup through LDS), a busy lane posts the bottom-most entries of its
+//    mesh-level stack (the subtrees it would reach LAST) on the workgroup's task
+//    board in LDS, and idle lanes of any wave of the workgroup take them; a wave
+//    without rays stays while another wave of its workgroup is busy.  The OWNER of
+//    the ray keeps the reference's exact sequential state for the part it traverses
+//    itself, which precedes every posted subtree in visiting order.  A HELPER
+//    traverses its subtree with a bound b that starts at the poster's bound and
+//    RECORDS every triangle it would accept, (triangle, t, tEnter of its leaf),
+//    lowering b only when t >= tEnter.  b is then never below the minT the reference
+//    has at the same point (by induction over the visiting order: the reference
+//    either accepts the same triangle, or rejects it because minT <= t, or culls the
+//    leaf because minT < tEnter <= t), so every triangle the reference accepts inside
+//    the subtree is among the recorded ones (box and triangle tests are monotone in
+//    the bound).  When the owner's own part is done and its count of outstanding
+//    subtrees is zero, it replays the candidates in visiting order (= ascending
+//    triangle slot: the builder partitions the primitive array in place,
+//    raytracer.cpp:247-262, and the left child is visited first) with the reference's
+//    rule: skip if minT culls the leaf box, accept if t < minT.  That is the
+//    reference's result exactly; what changes is that one long ray is traced by many
+//    lanes (the slowest ray of the 1M-triangle frame takes ~1000 sequential steps,
+//    longer than the rest of the kernel).  A ray with more than RT_CAND_MAX candidates
+//    re-traverses the mesh alone.  Bounded: a wave gives up after RT_ROUND_CAP rounds,
+//    an owner after RT_WAIT_ROUNDS_MAX rounds of waiting (reported as errors).
+//  * The node phase of a round ends when no lane can walk on — or when only a few
+//    still walk while others wait with queued leaves (the walkers keep their place).
 //
 // IO::load(item, o, d, time, minT, has, out) -> int  sets up the ray (plane loop
 //   included, raytracer.cpp:423-435 / :1022-1028) and returns 2, or stores a final
