@@ -14,7 +14,8 @@ For every scene listed below it writes, under tests/golden/:
                      where the reference repository holds its author's render of
                      the same scene with HEAD, the script asserts both are identical
   <name>.hits.npz    primary-hit identity per pixel straight from the reference's
-                     IntersectTopBVH / IntersectsPlane: kind, index, face i0,i1,i2, t bits
+                     IntersectTopBVH / IntersectsPlane: kind, index, face i0,i1,i2, t bits;
+                     `tile` = x0,y0,w,h of the rectangle the png and the hits cover
 Fixtures are data (inputs + expected outputs); no reference source is stored.
 """
 import gzip
@@ -49,6 +50,15 @@ SCENES = [
     ("hw3_cornellbox_area", "hw3/inputs/cornellbox_area.json", "hw3/my_outputs/cornellbox_area.png", None),
     ("hw3_metal_glass_plates", "hw3/inputs/metal_glass_plates.json", "hw3/my_outputs/metal_glass_plates.png", None),
     ("hw3_cornellbox_brushed_metal", "hw3/inputs/cornellbox_brushed_metal.json", "hw3/my_outputs/cornellbox_brushed_metal.png", None),
+    # meshes given inline in the JSON, area light + dielectric / conductor pieces, depth 6 (and depth of field);
+    # cropped where the full frame would take the reference many minutes: a tile's pixels do not depend on
+    # the rest of the frame (seed = i*width+j, raytracer.cpp:44)
+    ("hw3_chessboard_arealight", "hw3/inputs/ramazan_tokay/chessboard_arealight.json", "hw3/my_outputs/chessboard_arealight.png", (200, 300, 400, 200)),
+    ("hw3_chessboard_dof_glass_queen", "hw3/inputs/ramazan_tokay/chessboard_arealight_dof_glass_queen.json", "hw3/my_outputs/chessboard_arealight_dof_glass_queen.png", (200, 250, 400, 200)),
+    ("hw3_deadmau5", "hw3/inputs/ramazan_tokay/deadmau5_scene.json", "hw3/my_outputs/deadmau5.png", (200, 200, 400, 200)),
+    ("hw3_wine_glass", "hw3/inputs/ramazan_tokay/wine_glass_scene.json", "hw3/my_outputs/wine_glass.png", (300, 300, 200, 100)),
+    # one frame of the tap-water animation: binary PLY meshes, a rough (Roughness 0.25) material, 64 spp
+    ("hw3_tap_0100", "hw3/inputs/tap_water/json/tap_0100.json", "hw3/my_outputs/tap_water/tap_0100.png", (300, 400, 400, 200)),
 ]
 
 
@@ -68,13 +78,16 @@ def main():
         cam = CameraDesc()
         ob.ref().ref_camera(0, C.byref(cam))
         w, h = cam.image_width, cam.image_height
-        rgb, sec = ob.ref_render(0, 0, 0, w, h)
+        x0, y0 = 0, 0
+        if crop:
+            x0, y0, w, h = crop
+        rgb, sec = ob.ref_render(0, x0, y0, w, h)
         if author_png:
-            g = np.array(Image.open(REF + author_png).convert("RGB"))
+            g = np.array(Image.open(REF + author_png).convert("RGB"))[y0:y0 + h, x0:x0 + w]
             assert g.shape == rgb.shape and (g == rgb).all(), f"{name}: reference build differs from the author's render"
         Image.fromarray(rgb).save(os.path.join(HERE, name + ".png"), optimize=True)
-        hits = ob.ref_primary_hits(0, 0, 0, w, h)
-        np.savez_compressed(os.path.join(HERE, name + ".hits.npz"), hits=hits)
+        hits = ob.ref_primary_hits(0, x0, y0, w, h)
+        np.savez_compressed(os.path.join(HERE, name + ".hits.npz"), hits=hits, tile=np.array([x0, y0, w, h], np.int32))
         print(f"{name}: {w}x{h} spp={cam.num_samples} ref {sec:.1f}s  author-render-identical={bool(author_png)}", flush=True)
 
 

@@ -14,7 +14,10 @@ GOLD = ["hw1_simple", "hw1_spheres_mirror", "hw1_cornellbox_recursive", "hw1_two
         "hw2_mirror_room", "hw2_metal_glass_plates", "hw2_two_berserkers", "hw2_ellipsoids", "hw2_simple_transform",
         "hw3_spheres_dof", "hw3_cornellbox_boxes_dynamic",
         # shading draws random numbers (area light / Roughness > 0): the depth-first pixel loop of rt_ordered.h
-        "hw3_cornellbox_area", "hw3_cornellbox_brushed_metal", "hw3_metal_glass_plates"]
+        "hw3_cornellbox_area", "hw3_cornellbox_brushed_metal", "hw3_metal_glass_plates",
+        # tiles of the author's renders: inline meshes, area light with dielectric / conductor pieces at depth 6,
+        # depth of field, 900 spp, and a frame of the tap-water animation (binary PLY, rough material)
+        "hw3_chessboard_arealight", "hw3_chessboard_dof_glass_queen", "hw3_deadmau5", "hw3_wine_glass", "hw3_tap_0100"]
 
 
 @pytest.fixture(scope="module")
@@ -30,7 +33,8 @@ def test_golden_reference_scene(rt, name):
     hs = util.golden_scene(name)
     cam = hs.camera(0)
     ds = rt.DeviceScene(hs, 0)
-    rgb, hits = ds.render(cam, want_hits=True)
+    tile = util.golden_tile(name) or (0, 0, cam.image_width, cam.image_height)
+    rgb, hits = ds.render(cam, *tile, want_hits=True)
     ds.close()
     st = util.image_stats(rgb, util.golden_image(name))
     ok = util.hit_ids_match(hits, util.golden_hits(name))

@@ -36,6 +36,12 @@ def golden_hits(name):
     return np.load(os.path.join(GOLDEN, name + ".hits.npz"))["hits"]
 
 
+def golden_tile(name):
+    """(x0, y0, w, h) of the rectangle the fixture's png and hits cover, or None for the whole frame."""
+    z = np.load(os.path.join(GOLDEN, name + ".hits.npz"))
+    return tuple(int(v) for v in z["tile"]) if "tile" in z.files else None
+
+
 def hit_ids_match(hits_u32, ref6, scene_faces=None):
     """Fraction of pixels whose (kind, index) equal the reference's.  hits_u32: [h,w,2] as rt.h documents."""
     miss = hits_u32[..., 0] == 0xFFFFFFFF
