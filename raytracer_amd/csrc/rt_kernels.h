@@ -37,7 +37,7 @@ struct Control {
     uint32_t gstart[RT_MAX_GEN + 2];   // generation g = records [gstart[g], gstart[g+1])
     uint32_t sstart[RT_MAX_GEN + 2];   // shadow slots of generation g
     uint32_t n_records, n_shadow;      // allocation cursors
-    uint32_t cursor_closest, cursor_shadow;
+    uint32_t cursor_closest[RT_PARTS * RT_CURSOR_STRIDE], cursor_shadow[RT_PARTS * RT_CURSOR_STRIDE];   // one per partition, a line apart
     uint32_t overflow;                 // 1: record pool, 2: shadow pool, 4: traversal stack
     uint32_t pad;
     unsigned long long rays_primary, rays_secondary, rays_shadow;
@@ -183,8 +183,7 @@ __global__ void k_init_chunk(Control* ctl, uint32_t n_primary) {
         ctl->gstart[0] = 0;
         ctl->n_records = n_primary;
         ctl->n_shadow = 0;
-        ctl->cursor_closest = 0;
-        ctl->cursor_shadow = 0;
+        for (int p = 0; p < RT_PARTS; p++) { ctl->cursor_closest[p * RT_CURSOR_STRIDE] = 0; ctl->cursor_shadow[p * RT_CURSOR_STRIDE] = 0; }
         ctl->overflow = 0;
     }
 }
@@ -412,7 +411,7 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_closest(
 #endif
     unsigned long long traced = 0;   // wave-uniform
     ClosestIO io{S, P};
-    trace_persistent<false, true>(S, io, begin, end, &ctl->cursor_closest, st, traced);
+    trace_persistent<false, true>(S, io, begin, end, ctl->cursor_closest, st, traced);
     if (st.overflow) atomicOr(&ctl->overflow, (st.overflow & 48u) | ((st.overflow & ~48u) ? 4u : 0u));
 #ifdef RT_TRACE_STATS
 #ifndef RT_STATS_SHADOW
@@ -464,7 +463,7 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_shadow(D
 #endif
     unsigned long long traced = 0;
     ShadowIO io{S, P};
-    trace_persistent<true, true>(S, io, begin, end, &ctl->cursor_shadow, st, traced);
+    trace_persistent<true, true>(S, io, begin, end, ctl->cursor_shadow, st, traced);
 #if defined(RT_TRACE_STATS) && defined(RT_STATS_SHADOW)
     report_trace_stats(ctl, acc, traced, clk_start, st, ww);
 #endif
@@ -701,8 +700,7 @@ __global__ void k_advance(Control* ctl, Pool P, int gen) {
         ctl->n_shadow = ns;
         for (int g = gen + 2; g < RT_MAX_GEN + 2; g++) ctl->gstart[g] = nr;
         for (int g = gen + 1; g < RT_MAX_GEN + 2; g++) ctl->sstart[g] = ns;
-        ctl->cursor_closest = 0;
-        ctl->cursor_shadow = 0;
+        for (int p = 0; p < RT_PARTS; p++) { ctl->cursor_closest[p * RT_CURSOR_STRIDE] = 0; ctl->cursor_shadow[p * RT_CURSOR_STRIDE] = 0; }
     }
 }
 

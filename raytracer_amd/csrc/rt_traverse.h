@@ -73,6 +73,13 @@
 #ifndef RT_STRIP
 #define RT_STRIP 8               // closest-hit: consecutive items of a 64-item block handed out together (divides 64)
 #endif
+#ifndef RT_PARTS
+#define RT_PARTS 8               // cursor partitions of a generation (XCDs of the chip)
+#endif
+#ifndef RT_PARTS_MIN_BLOCKS
+#define RT_PARTS_MIN_BLOCKS 4096 // 64-item blocks below which a generation keeps one cursor
+#endif
+#define RT_CURSOR_STRIDE 32u     // words between the partitions' cursors (a 128-byte line each)
 #ifndef RT_STRIP_ANY
 #define RT_STRIP_ANY 64          // any-hit: shadow slots of one record are neighbours and differ in direction; keep blocks whole
 #endif
@@ -430,16 +437,25 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
     // walks the blocks strip by strip: strip 0 (RT_STRIP items) of every block, then strip 1 of every block,
     // ...  A 64-lane refill then takes one strip from each of 64/RT_STRIP neighbouring blocks (for primary
     // rays a line of pixels), and the rays of one block are spread over 64/RT_STRIP waves and moments.
-    const uint32_t n_blocks = (end - begin + 63u) / 64u, n_padded = n_blocks * 64u;
+    const uint32_t n_blocks = (end - begin + 63u) / 64u;
+    // A large generation is cut into RT_PARTS contiguous partitions, each with a cursor of its own, and a
+    // workgroup starts on partition blockIdx % RT_PARTS: the workgroups that share an XCD work on one part of
+    // the image (of the record pool), so that XCD's L2 holds that part's share of the BVH instead of all of it.
+    const uint32_t parts = (LINGER && n_blocks >= RT_PARTS_MIN_BLOCKS) ? (uint32_t)RT_PARTS : 1u;
+    const uint32_t part0 = LINGER ? blockIdx.x % parts : 0u;
+    uint32_t parts_done = 0;     // wave-uniform: partitions this wave knows to be drained
     uint32_t stale = 0;          // wave-uniform: rounds with idle lanes since the last refill
     st.sp = 0;
 
     for (;;) {
         RT_CLK(c0);
         // ---- refill idle lanes
-        if (!exhausted && st.blk[4] != 0) {          // another wave of the workgroup has seen the cursor drained
-            exhausted = true;
-            RT_STAT(st.acc->clk_exhausted = wall_clock64();)
+        if (LINGER && !exhausted) {                  // partitions other waves of the workgroup have seen drained
+            const uint32_t d = st.blk[4];
+            if (d > parts_done) {
+                parts_done = d;
+                if (parts_done >= parts) { exhausted = true; RT_STAT(st.acc->clk_exhausted = wall_clock64();) }
+            }
         }
         if (!exhausted) {
             const uint64_t idle = __ballot(!alive);
@@ -450,19 +466,31 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             stale = n_idle != 0 ? stale + 1 : 0;
             if (n_idle >= REFILL_MIN || stale > RT_REFILL_PATIENCE) {
                 stale = 0;
+                // the partition this workgroup draws from: its own (blockIdx % parts: workgroups that share an
+                // XCD, hence an L2, share a partition), then the others in turn
+                const uint32_t part = (part0 + parts_done) % parts;
+                const uint32_t pb0 = (uint32_t)((uint64_t)n_blocks * part / parts);
+                const uint32_t pnb = (uint32_t)((uint64_t)n_blocks * (part + 1u) / parts) - pb0, p_padded = pnb * 64u;
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(cursor, n_idle);
+                if (lane == 0) base = atomicAdd(cursor + part * RT_CURSOR_STRIDE, n_idle);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (base + n_idle >= n_padded) { exhausted = true; if (LINGER && lane == 0) st.blk[4] = 1u; RT_STAT(st.acc->clk_exhausted = wall_clock64();) }
+                if (base + n_idle >= p_padded) {
+                    parts_done++;
+                    if (LINGER && lane == 0) atomicMax(&st.blk[4], parts_done);
+                    if (parts_done >= parts) { exhausted = true; RT_STAT(st.acc->clk_exhausted = wall_clock64();) }
+                    else stale = RT_REFILL_PATIENCE + 1u;     // lanes left empty try the next partition at once
+                }
                 int got = 0;
                 if (!alive) {
-                    // cursor value -> item: strip-interleaved over the 64-item blocks (see above)
+                    // cursor value -> item: strip-interleaved over the partition's 64-item blocks (see above)
                     const uint32_t c = base + (uint32_t)__popcll(idle & lanes_below);
-                    const uint32_t strip = c / STRIP, within = c % STRIP;
-                    const uint32_t i = begin + (strip % n_blocks) * 64u + (strip / n_blocks) * STRIP + within;
-                    if (c < n_padded && i < end) {
-                        item = i;
-                        got = io.load(i, ro, rd, time, minT, has, out);
+                    if (c < p_padded) {
+                        const uint32_t strip = c / STRIP, within = c % STRIP;
+                        const uint32_t i = begin + (pb0 + strip % pnb) * 64u + (strip / pnb) * STRIP + within;
+                        if (i < end) {
+                            item = i;
+                            got = io.load(i, ro, rd, time, minT, has, out);
+                        }
                     }
                 }
                 traced += __popcll(__ballot(got != 0));
