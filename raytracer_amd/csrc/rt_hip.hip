@@ -417,6 +417,7 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
     D.big_leaves = (const DBigLeaf*)sc->b_big.p;
     D.n_big_leaves = (uint32_t)big.size();
     D.donate_ok = donate_ok ? 1u : 0u;
+    if (getenv("RT_NO_DONATE")) D.donate_ok = 0u;      // diagnostic: every ray is traced by its owner alone
     D.tris = (const DTri*)sc->b_tris.p;
     D.tri_shade = (const DTriShade*)sc->b_tri_shade.p;
     D.vnormals = (const float4*)sc->b_vnormals.p;
@@ -670,6 +671,29 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
                     fprintf(stderr, "[rt stats] wave %d: life %.0f us exhausted@%.0f | sched %.0f node %.0f tri %.0f big %.0f trans %.0f us | outer %llu nodesteps %llu (lanes %llu) tristeps %llu (lanes %llu) donations %llu coop %llu rays %llu\n",
                             order[r], o[0] * 0.01, o[1] * 0.01, o[2] * 0.01, o[3] * 0.01, o[4] * 0.01, o[5] * 0.01, o[6] * 0.01, o[7], o[8], o[13], o[9], o[14], o[10], o[11], o[12]);
                 }
+            }
+        }
+        {   // chip-wide activity over time: wave steps and active lanes per 25-us bin (both trace kernels of the frame add up)
+            static unsigned long long hh[RT_HIST_BINS][4];
+            if (hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_hist), sizeof(hh)) == hipSuccess) {
+                for (int b = 0; b < RT_HIST_BINS; b++)
+                    if (hh[b][0] | hh[b][2])
+                        fprintf(stderr, "[rt hist] %5d us: node steps %7llu util %.2f | tri steps %7llu util %.2f\n", b * 25, hh[b][0],
+                                hh[b][0] ? hh[b][1] / (64.0 * hh[b][0]) : 0.0, hh[b][2], hh[b][2] ? hh[b][3] / (64.0 * hh[b][2]) : 0.0);
+                std::memset(hh, 0, sizeof(hh));
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hist), hh, sizeof(hh));
+            }
+        }
+        {
+            static unsigned long long rh[2][20];
+            if (hipMemcpyFromSymbol(rh, HIP_SYMBOL(g_rayhist), sizeof(rh)) == hipSuccess) {
+                for (int k = 0; k < 2; k++) {
+                    fprintf(stderr, "[rt rayhist] %s per ray (0, 1, 2-3, 4-7, ...):", k ? "node steps" : "leaves");
+                    for (int b = 0; b < 20; b++) fprintf(stderr, " %llu", rh[k][b]);
+                    fprintf(stderr, "\n");
+                }
+                std::memset(rh, 0, sizeof(rh));
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rayhist), rh, sizeof(rh));
             }
         }
         fprintf(stderr, "[rt stats] board: donor-eligible lane-rounds %llu, gated by idle<=ready %llu, slot busy %llu, claims %llu\n", d[6], d[7], d[8], d[9]);

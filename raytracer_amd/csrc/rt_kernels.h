@@ -408,6 +408,7 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_closest(
     TraceStatsAcc acc = {};
     st.acc = &acc;
     const unsigned long long clk_start = wall_clock64();
+    acc.clk_start = clk_start;
 #endif
     unsigned long long traced = 0;   // wave-uniform
     ClosestIO io{S, P};
@@ -460,6 +461,7 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_shadow(D
     TraceStatsAcc acc = {};
     st.acc = &acc;
     const unsigned long long clk_start = wall_clock64();
+    acc.clk_start = clk_start;
 #endif
     unsigned long long traced = 0;
     ShadowIO io{S, P};

@@ -73,6 +73,9 @@
 #ifndef RT_STRIP
 #define RT_STRIP 8               // closest-hit: consecutive items of a 64-item block handed out together (divides 64)
 #endif
+#ifndef RT_TRI_UNROLL
+#define RT_TRI_UNROLL 2          // triangles of a queued leaf a lane loads together
+#endif
 #ifndef RT_PARTS
 #define RT_PARTS 8               // cursor partitions of a generation (XCDs of the chip)
 #endif
@@ -130,10 +133,21 @@
 #ifdef RT_TRACE_STATS
 struct TraceStatsAcc {
     unsigned long long wave_node_steps, lane_node_steps, wave_tri_steps, lane_tri_steps, wave_outer, lane_rays, wave_batches, wave_pops, lane_pops;
+    unsigned int ray_leaves, ray_nodes;
+    unsigned long long clk_start, r_node_w, r_node_l, r_tri_w, r_tri_l;   // activity histogram (flushed every round)
     unsigned long long t_sched, t_node, t_tri, t_big, t_trans, clk_exhausted, n_donations, n_coop, n_replays, n_elig, n_gate, n_casfail, n_claim, n_culled;
 };
 #define RT_CLK(v) const unsigned long long v = wall_clock64()
 #define RT_STAT(x) x
+#ifdef RT_STATS_SHADOW
+#define RT_HIST_ANY true
+#else
+#define RT_HIST_ANY false
+#endif
+#define RT_HIST_BINS 128
+#define RT_HIST_TICKS 2500ull     // 25 us per bin (wall_clock64 ticks are 10 ns)
+__device__ unsigned long long g_hist[RT_HIST_BINS][4];
+__device__ unsigned long long g_rayhist[2][20];   // [0]: rays by log2(leaves visited), [1]: by log2(node steps); owner lanes only
 #else
 #define RT_STAT(x)
 #define RT_CLK(v)
@@ -449,71 +463,11 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
 
     for (;;) {
         RT_CLK(c0);
-        // ---- refill idle lanes
         if (LINGER && !exhausted) {                  // partitions other waves of the workgroup have seen drained
             const uint32_t d = st.blk[4];
             if (d > parts_done) {
                 parts_done = d;
                 if (parts_done >= parts) { exhausted = true; RT_STAT(st.acc->clk_exhausted = wall_clock64();) }
-            }
-        }
-        if (!exhausted) {
-            const uint64_t idle = __ballot(!alive);
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
-            // A wave that keeps a few idle lanes for RT_REFILL_PATIENCE rounds refills them anyway: they
-            // would otherwise wait for the slowest rays, and the attempt is also how the wave learns that
-            // the cursor is drained (from then on idle lanes help the busy ones, see subtree donation).
-            stale = n_idle != 0 ? stale + 1 : 0;
-            if (n_idle >= REFILL_MIN || stale > RT_REFILL_PATIENCE) {
-                stale = 0;
-                // the partition this workgroup draws from: its own (blockIdx % parts: workgroups that share an
-                // XCD, hence an L2, share a partition), then the others in turn
-                const uint32_t part = (part0 + parts_done) % parts;
-                const uint32_t pb0 = (uint32_t)((uint64_t)n_blocks * part / parts);
-                const uint32_t pnb = (uint32_t)((uint64_t)n_blocks * (part + 1u) / parts) - pb0, p_padded = pnb * 64u;
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(cursor + part * RT_CURSOR_STRIDE, n_idle);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (base + n_idle >= p_padded) {
-                    parts_done++;
-                    if (LINGER && lane == 0) atomicMax(&st.blk[4], parts_done);
-                    if (parts_done >= parts) { exhausted = true; RT_STAT(st.acc->clk_exhausted = wall_clock64();) }
-                    else stale = RT_REFILL_PATIENCE + 1u;     // lanes left empty try the next partition at once
-                }
-                int got = 0;
-                if (!alive) {
-                    // cursor value -> item: strip-interleaved over the partition's 64-item blocks (see above)
-                    const uint32_t c = base + (uint32_t)__popcll(idle & lanes_below);
-                    if (c < p_padded) {
-                        const uint32_t strip = c / STRIP, within = c % STRIP;
-                        const uint32_t i = begin + (pb0 + strip % pnb) * 64u + (strip / pnb) * STRIP + within;
-                        if (i < end) {
-                            item = i;
-                            got = io.load(i, ro, rd, time, minT, has, out);
-                        }
-                    }
-                }
-                traced += __popcll(__ballot(got != 0));
-                if (got == 2) {
-                    alive = true;
-                    helper = false;
-                    home = st.slot;
-                    st.sp = 0;
-                    in_mesh = false;
-                    donated = false;
-                    no_donate = false;
-                    qn = 0;
-                    ar.set(ro, rd);
-                    tmax = minT;
-                    cur = RT_LINK_DONE;
-                    if (S.top_root_link != RT_LINK_DONE) {
-                        float te;
-                        if (box_test(ar, S.top_rmin[0], S.top_rmin[1], S.top_rmin[2], S.top_rmax[0], S.top_rmax[1], S.top_rmax[2], tmax, te)) {
-                            cur = S.top_root_link;
-                            cur_t = te;
-                        }
-                    }
-                }
             }
         }
         // ---- subtree donation over the workgroup's task board (see the header)
@@ -615,8 +569,8 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         }
 
         // ---- nothing to do in this wave: leave, or stay to help the workgroup
-        if (!__any(alive)) {
-            if (!exhausted) continue;
+        const bool any_alive = __any(alive);
+        if (!any_alive && exhausted) {
             if (was_busy) {
                 was_busy = false;
                 if (lane == 0) atomicSub(&st.blk[0], 1u);
@@ -630,7 +584,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             __builtin_amdgcn_s_sleep(32);
             continue;
         }
-        if (!was_busy) {
+        if (any_alive && !was_busy) {
             was_busy = true;
             if (lane == 0) atomicAdd(&st.blk[0], 1u);
         }
@@ -654,12 +608,14 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             }
             if (want) {
                 if (leaf_here) {
+                    RT_STAT(st.acc->ray_leaves++;)
                     st.q[qn * 64 + st.lane] = make_uint2(cur, __float_as_uint(cur_t));
                     qn++;
                     cur = st.pop(tmax, cur_t);
                 }
                 if (!(cur & RT_LINK_LEAF)) {
-                    RT_STAT({ unsigned long long m = __ballot(1); if (st.lane == __ffsll((long long)m) - 1) { st.acc->wave_node_steps++; st.acc->lane_node_steps += __popcll(m); } })
+                    RT_STAT(st.acc->ray_nodes++;)
+                    RT_STAT({ unsigned long long m = __ballot(1); if (st.lane == __ffsll((long long)m) - 1) { st.acc->wave_node_steps++; st.acc->lane_node_steps += __popcll(m); st.acc->r_node_w++; st.acc->r_node_l += __popcll(m); } })
                     const float4* p = reinterpret_cast<const float4*>(&S.nodes[cur]);
                     const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
                     const uint4 lk = reinterpret_cast<const uint4*>(p)[6];
@@ -732,16 +688,31 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             if ((tmax < te) || (te == 0.0f && tmax <= 0.0f)) continue;   // the reference would cull this leaf's box now
             uint32_t ti = RT_LEAF_FIRST(link);
             uint32_t n = RT_LEAF_COUNT(link);                            // < RT_LEAF_BIG: big leaves are never queued
-            for (; n != 0; n--, ti++) {
-                RT_STAT({ unsigned long long m = __ballot(1); if (st.lane == __ffsll((long long)m) - 1) { st.acc->wave_tri_steps++; st.acc->lane_tri_steps += __popcll(m); } })
-                // 36-byte record as dwordx4 + dwordx4 + dword, all issued before the test
-                const float* tp = reinterpret_cast<const float*>(&S.tris[ti]);
-                const f4u ta = *reinterpret_cast<const f4u*>(tp), tb = *reinterpret_cast<const f4u*>(tp + 4);
-                const float tc = tp[8];
-                float t, bb, gg;
-                if (tri_test(ar, ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w, tc, tmax, t, bb, gg)) {
-                    if (accept(ti, t, bb, gg, te)) { fin = true; break; }
+            // RT_TRI_UNROLL triangles are loaded before the first is tested; they are tested one after the other
+            // against the bound the previous one left, as the reference's loop does.  Past the leaf's end a lane
+            // re-reads the leaf's first triangle.
+            while (n != 0 && !fin) {
+                RT_STAT({ unsigned long long m = __ballot(1); if (st.lane == __ffsll((long long)m) - 1) { st.acc->wave_tri_steps++; st.acc->lane_tri_steps += __popcll(m); st.acc->r_tri_w++; st.acc->r_tri_l += __popcll(m); } })
+                const uint32_t m = n < (uint32_t)RT_TRI_UNROLL ? n : (uint32_t)RT_TRI_UNROLL;
+                f4u ta[RT_TRI_UNROLL], tb[RT_TRI_UNROLL];
+                float tc[RT_TRI_UNROLL];
+#pragma unroll
+                for (uint32_t u = 0; u < RT_TRI_UNROLL; u++) {
+                    // 36-byte record as dwordx4 + dwordx4 + dword, all issued before the tests
+                    const float* tp = reinterpret_cast<const float*>(&S.tris[ti + (u < m ? u : 0u)]);
+                    ta[u] = *reinterpret_cast<const f4u*>(tp);
+                    tb[u] = *reinterpret_cast<const f4u*>(tp + 4);
+                    tc[u] = tp[8];
                 }
+#pragma unroll
+                for (uint32_t u = 0; u < RT_TRI_UNROLL; u++) {
+                    float t, bb, gg;
+                    if (u < m && !fin && tri_test(ar, ta[u].x, ta[u].y, ta[u].z, ta[u].w, tb[u].x, tb[u].y, tb[u].z, tb[u].w, tc[u], tmax, t, bb, gg)) {
+                        if (accept(ti + u, t, bb, gg, te)) fin = true;
+                    }
+                }
+                n -= m;
+                ti += m;
             }
         }
         qn = 0;
@@ -823,8 +794,11 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             if (cur != RT_LINK_SENTINEL) cur = st.pop(-1.0f, cur_t);   // (the sentinel may already have been popped)
         }
 
-        // ---- per-lane transitions between the levels
+        // ---- per-lane transitions between the levels; then idle lanes are refilled from the cursor, and the new
+        // rays make their first transition (top-level entry, raytracer.cpp:548-745) at once, in a second pass,
+        // instead of sitting through a whole round before it
         RT_CLK(c4);
+        for (int tpass = 0;; tpass++) {
         bool finished = fin;
         if (alive && !fin) do {
             if (!(cur & RT_LINK_LEAF)) break;          // still on an interior record (the node phase was left early)
@@ -984,8 +958,10 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 atomicSub(&st.out_cnt[home], 1u);
             } else {
+                RT_STAT({ if (ANYHIT == RT_HIST_ANY) { atomicAdd(&g_rayhist[0][32 - __clz(st.acc->ray_leaves)], 1ull); atomicAdd(&g_rayhist[1][32 - __clz(st.acc->ray_nodes)], 1ull); } })
                 io.store(item, ANYHIT ? fin : has, out, minT);
             }
+            RT_STAT(st.acc->ray_leaves = 0; st.acc->ray_nodes = 0;)
             alive = false;
             helper = false;
             in_mesh = false;
@@ -994,6 +970,77 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             cur = RT_LINK_DONE;
             st.sp = 0;
         }
+        if (tpass != 0 || exhausted) break;
+        // ---- refill idle lanes
+        bool refilled = false;
+        if (!exhausted) {
+            const uint64_t idle = __ballot(!alive);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            // A wave that keeps a few idle lanes for RT_REFILL_PATIENCE rounds refills them anyway: they
+            // would otherwise wait for the slowest rays, and the attempt is also how the wave learns that
+            // the cursor is drained (from then on idle lanes help the busy ones, see subtree donation).
+            stale = n_idle != 0 ? stale + 1 : 0;
+            if (n_idle >= REFILL_MIN || stale > RT_REFILL_PATIENCE) {
+                stale = 0;
+                // the partition this workgroup draws from: its own (blockIdx % parts: workgroups that share an
+                // XCD, hence an L2, share a partition), then the others in turn
+                const uint32_t part = (part0 + parts_done) % parts;
+                const uint32_t pb0 = (uint32_t)((uint64_t)n_blocks * part / parts);
+                const uint32_t pnb = (uint32_t)((uint64_t)n_blocks * (part + 1u) / parts) - pb0, p_padded = pnb * 64u;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(cursor + part * RT_CURSOR_STRIDE, n_idle);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base + n_idle >= p_padded) {
+                    parts_done++;
+                    if (LINGER && lane == 0) atomicMax(&st.blk[4], parts_done);
+                    if (parts_done >= parts) { exhausted = true; RT_STAT(st.acc->clk_exhausted = wall_clock64();) }
+                    else stale = RT_REFILL_PATIENCE + 1u;     // lanes left empty try the next partition at once
+                }
+                int got = 0;
+                if (!alive) {
+                    // cursor value -> item: strip-interleaved over the partition's 64-item blocks (see above)
+                    const uint32_t c = base + (uint32_t)__popcll(idle & lanes_below);
+                    if (c < p_padded) {
+                        const uint32_t strip = c / STRIP, within = c % STRIP;
+                        const uint32_t i = begin + (pb0 + strip % pnb) * 64u + (strip / pnb) * STRIP + within;
+                        if (i < end) {
+                            item = i;
+                            got = io.load(i, ro, rd, time, minT, has, out);
+                        }
+                    }
+                }
+                traced += __popcll(__ballot(got != 0));
+                refilled = __any(got == 2);
+                if (got == 2) {
+                    fin = false;
+                    alive = true;
+                    helper = false;
+                    home = st.slot;
+                    st.sp = 0;
+                    in_mesh = false;
+                    donated = false;
+                    no_donate = false;
+                    qn = 0;
+                    ar.set(ro, rd);
+                    tmax = minT;
+                    cur = RT_LINK_DONE;
+                    if (S.top_root_link != RT_LINK_DONE) {
+                        float te;
+                        if (box_test(ar, S.top_rmin[0], S.top_rmin[1], S.top_rmin[2], S.top_rmax[0], S.top_rmax[1], S.top_rmax[2], tmax, te)) {
+                            cur = S.top_root_link;
+                            cur_t = te;
+                        }
+                    }
+                }
+            }
+        }
+        if (!refilled) break;
+        }
+        RT_STAT({ unsigned long long b = (c0 - st.acc->clk_start) / RT_HIST_TICKS; if (b >= RT_HIST_BINS) b = RT_HIST_BINS - 1;
+                  if (ANYHIT != RT_HIST_ANY) { st.acc->r_node_w = 0; st.acc->r_tri_w = 0; }
+                  if (st.acc->r_node_w) { atomicAdd(&g_hist[b][0], st.acc->r_node_w); atomicAdd(&g_hist[b][1], st.acc->r_node_l); }
+                  if (st.acc->r_tri_w) { atomicAdd(&g_hist[b][2], st.acc->r_tri_w); atomicAdd(&g_hist[b][3], st.acc->r_tri_l); }
+                  st.acc->r_node_w = st.acc->r_node_l = st.acc->r_tri_w = st.acc->r_tri_l = 0; })
         RT_STAT({ const unsigned long long c5 = wall_clock64(); st.acc->t_sched += c1 - c0; st.acc->t_node += c2 - c1; st.acc->t_tri += c3 - c2; st.acc->t_big += c4 - c3; st.acc->t_trans += c5 - c4; })
     }
 }
