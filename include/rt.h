@@ -252,6 +252,24 @@ int rt_device_count(void);
  * at raytracer.cpp:30.  Synchronous. */
 int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out);
 
+/* Next frame of an animation whose meshes do not change: re-derive everything
+ * in `scene` except the mesh level (mesh_bvhs, mesh_nodes, mesh_prim_face,
+ * faces, vertex_data must be what rt_upload_scene saw) and keep the mesh BVHs,
+ * triangle records and shading data resident on the device.  What may change:
+ * object transforms / motion blur / materials (meshes, spheres, triangles),
+ * the top-level BVH and its prims, planes, materials, point and area lights,
+ * background, ambient, epsilon, recursion depth (the camera is an argument of
+ * the render calls anyway).  The reference renders an animation as one process
+ * per frame (render_and_make_gif.sh:102-119: parse, BuildAllMeshBVHs,
+ * BuildTopLevelBVH, render — raytracer.cpp:20-33 — for every JSON); with this
+ * call only the per-frame part of that set-up is repeated.
+ * flags: RT_UPDATE_VERIFY_MESHES compares a 64-bit hash of the mesh arrays with
+ * the one recorded at upload (array sizes are always compared) and fails with
+ * RT_ERR_INVALID on a difference.  Synchronous; no render call of this scene
+ * may be in flight. */
+enum { RT_UPDATE_VERIFY_MESHES = 1u };
+int rt_update_scene(rt_scene* s, const rt_scene_desc* scene, uint32_t flags);
+
 int rt_scene_set_option(rt_scene* s, int option, uint64_t value);
 
 /* Render the pixel rectangle [x0,x0+tile_w) x [y0,y0+tile_h) of camera `cam`

@@ -51,6 +51,20 @@ struct DevBuf {
         bytes = need;
         return RT_OK;
     }
+    // grow to `need` bytes, keeping the first `keep` bytes (device-to-device copy)
+    int grow_keep(size_t need, size_t keep) {
+        if (need <= bytes) return RT_OK;
+        void* q = nullptr;
+        HIPCHK(hipMalloc(&q, need));
+        if (p && keep) {
+            hipError_t e = hipMemcpy(q, p, keep, hipMemcpyDeviceToDevice);
+            if (e != hipSuccess) { (void)hipFree(q); return fail(RT_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e)); }
+        }
+        if (p) (void)hipFree(p);
+        p = q;
+        bytes = need;
+        return RT_OK;
+    }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
@@ -66,6 +80,7 @@ enum TimeCat { TC_RAYGEN, TC_CLOSEST, TC_SHADE, TC_SHADOW, TC_COMBINE, TC_RESOLV
 
 }  // namespace
 
+struct MeshRoot { uint32_t root_link; float rmin[3], rmax[3]; };
 struct rt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -78,6 +93,15 @@ struct rt_scene {
     bool has_reflective = false;      // any material with type != None
     bool needs_sequential_rng = false;   // area lights or rough reflective materials (RNG drawn while shading)
     uint32_t n_point_lights = 0, n_area_lights = 0;
+    // what rt_update_scene keeps: the mesh level as laid out by rt_upload_scene
+    struct MeshLevel {
+        std::vector<struct MeshRoot> roots;        // per mesh BVH: root link + root box
+        std::vector<DBigLeaf> big;                  // big leaves of the mesh BVHs
+        uint32_t n_node_records = 0;                // DNode4 records of the mesh BVHs (the top level follows them)
+        uint32_t n_mesh_bvhs = 0, n_mesh_nodes = 0, n_mesh_prims = 0, n_faces = 0, n_vertices = 0;
+        uint64_t hash = 0;                          // of the mesh arrays of the rt_scene_desc
+        bool donate_ok = true;
+    } mesh;
 
     // work memory
     Pool pool{};
@@ -118,7 +142,7 @@ int validate_bvh(const rt_bvh_node* nodes, uint32_t count, uint32_t n_prims, con
     return RT_OK;
 }
 
-int validate_scene(const rt_scene_desc* s) {
+int validate_scene(const rt_scene_desc* s, bool mesh_geometry = true) {
     if (!s) return fail(RT_ERR_INVALID, "scene is NULL");
     if (s->n_materials == 0) return fail(RT_ERR_INVALID, "scene has no materials");
     auto mat_ok = [&](int32_t id) { return id >= 1 && (uint32_t)id <= s->n_materials; };
@@ -132,7 +156,7 @@ int validate_scene(const rt_scene_desc* s) {
                      : p.kind == RT_KIND_TRIANGLE ? s->n_triangles : 0;
         if (p.index >= lim) return fail(RT_ERR_INVALID, "top prim %u: bad kind/index", i);
     }
-    for (uint32_t b = 0; b < s->n_mesh_bvhs; b++) {
+    for (uint32_t b = 0; mesh_geometry && b < s->n_mesh_bvhs; b++) {
         const rt_mesh_bvh& mb = s->mesh_bvhs[b];
         if ((uint64_t)mb.node_offset + mb.node_count > s->n_mesh_nodes || (uint64_t)mb.prim_offset + mb.prim_count > s->n_mesh_prims ||
             (uint64_t)mb.face_offset + mb.face_count > s->n_faces)
@@ -181,6 +205,7 @@ struct BvhBuilder4 {
     bool top;
     std::vector<DNode4>& out;
     std::vector<DBigLeaf>& big;
+    uint32_t base;          // record index of out[0] in the device array
 
     uint32_t leaf_link(const rt_bvh_node& n) {
         const uint32_t first = leaf_base + (uint32_t)n.left_or_first;
@@ -195,7 +220,7 @@ struct BvhBuilder4 {
     uint32_t build(uint32_t root) {
         struct Item { uint32_t ref_node, slot; };
         std::vector<Item> work;
-        const uint32_t root_slot = (uint32_t)out.size();
+        const uint32_t root_slot = base + (uint32_t)out.size();
         out.emplace_back();
         work.push_back({root, root_slot});
         while (!work.empty()) {
@@ -213,7 +238,7 @@ struct BvhBuilder4 {
                 if (c.prim_count > 0) {
                     d.link[slot] = leaf_link(c);
                 } else {
-                    const uint32_t ns = (uint32_t)out.size();
+                    const uint32_t ns = base + (uint32_t)out.size();
                     out.emplace_back();
                     d.link[slot] = ns;
                     work.push_back({ref, ns});
@@ -231,16 +256,16 @@ struct BvhBuilder4 {
                 s += 2;
             }
             // slot 0 must be valid for the device's fast path; it is, since the left child always fills slot 0
-            out[it.slot] = d;
+            out[it.slot - base] = d;
         }
         return root_slot;
     }
 };
 BvhLayout layout_bvh(const rt_bvh_node* nodes, uint32_t count, uint32_t leaf_base, bool top, std::vector<DNode4>& out,
-                     std::vector<DBigLeaf>& big) {
+                     std::vector<DBigLeaf>& big, uint32_t base = 0) {
     BvhLayout L;
     if (count == 0) return L;
-    BvhBuilder4 b{nodes, leaf_base, top, out, big};
+    BvhBuilder4 b{nodes, leaf_base, top, out, big, base};
     L.root_link = nodes[0].prim_count > 0 ? b.leaf_link(nodes[0]) : b.build(0);
     std::memcpy(L.rmin, nodes[0].bmin, 12);
     std::memcpy(L.rmax, nodes[0].bmax, 12);
@@ -279,7 +304,31 @@ void fill_object_common(DObject& o, uint32_t flags, const float* M, const float*
     o.root_link = RT_LINK_DONE;
 }
 
-int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
+// 64-bit hash of the mesh arrays of a scene description (what rt_update_scene must find unchanged)
+uint64_t hash_bytes(uint64_t h, const void* p, size_t n) {
+    const uint8_t* b = (const uint8_t*)p;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        std::memcpy(&w, b + i, 8);
+        h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+    }
+    for (; i < n; i++) h = (h ^ b[i]) * 0x100000001B3ull;
+    return h;
+}
+uint64_t mesh_hash(const rt_scene_desc* s) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    h = hash_bytes(h, s->mesh_bvhs, sizeof(rt_mesh_bvh) * s->n_mesh_bvhs);
+    h = hash_bytes(h, s->mesh_nodes, sizeof(rt_bvh_node) * s->n_mesh_nodes);
+    h = hash_bytes(h, s->mesh_prim_face, sizeof(uint32_t) * s->n_mesh_prims);
+    h = hash_bytes(h, s->faces, sizeof(rt_face) * s->n_faces);
+    h = hash_bytes(h, s->vertex_data, sizeof(rt_vertex) * s->n_vertices);
+    return h;
+}
+
+// The mesh level: collapsed mesh BVHs, leaf-ordered triangle records, shading data, vertex normals.
+int build_mesh_level(rt_scene* sc, const rt_scene_desc* s) {
     std::vector<DNode4> nodes;
     std::vector<DBigLeaf> big;
     std::vector<DTri> tris(s->n_mesh_prims);
@@ -310,6 +359,44 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
         }
     }
 
+    std::vector<float4> vn(s->n_vertices);
+    for (uint32_t i = 0; i < s->n_vertices; i++)
+        vn[i] = make_float4(s->vertex_data[i].normal[0], s->vertex_data[i].normal[1], s->vertex_data[i].normal[2], 0.f);
+    if (nodes.size() >= 0x7FFFFFF0u - 2ull * s->n_top_nodes || tris.size() >= RT_LEAF_MAX_FIRST)
+        return fail(RT_ERR_UNSUPPORTED, "scene too large for the link encoding (2^26 leaf prims)");
+
+    int rc;
+    // the top level's records follow the meshes' in the same array: leave room for them (rt_update_scene grows it if needed)
+    if ((rc = sc->b_nodes.ensure((nodes.size() + std::max<size_t>(1024, 2 * (size_t)s->n_top_nodes)) * sizeof(DNode4)))) return rc;
+    if (!nodes.empty()) HIPCHK(hipMemcpy(sc->b_nodes.p, nodes.data(), nodes.size() * sizeof(DNode4), hipMemcpyHostToDevice));
+    if ((rc = upload_vec(sc->b_tris, tris)) || (rc = upload_vec(sc->b_tri_shade, tshade)) || (rc = upload_vec(sc->b_vnormals, vn))) return rc;
+
+    rt_scene::MeshLevel& M = sc->mesh;
+    M.roots.resize(s->n_mesh_bvhs);
+    for (uint32_t b = 0; b < s->n_mesh_bvhs; b++) {
+        M.roots[b].root_link = mesh_layout[b].root_link;
+        std::memcpy(M.roots[b].rmin, mesh_layout[b].rmin, 12);
+        std::memcpy(M.roots[b].rmax, mesh_layout[b].rmax, 12);
+    }
+    M.big = big;
+    M.n_node_records = (uint32_t)nodes.size();
+    M.n_mesh_bvhs = s->n_mesh_bvhs; M.n_mesh_nodes = s->n_mesh_nodes; M.n_mesh_prims = s->n_mesh_prims;
+    M.n_faces = s->n_faces; M.n_vertices = s->n_vertices;
+    M.hash = mesh_hash(s);
+    M.donate_ok = donate_ok;
+    sc->ds.tris = (const DTri*)sc->b_tris.p;
+    sc->ds.tri_shade = (const DTriShade*)sc->b_tri_shade.p;
+    sc->ds.vnormals = (const float4*)sc->b_vnormals.p;
+    return RT_OK;
+}
+
+// Everything else: objects (transforms, motion blur, materials), the top-level BVH, planes, materials, lights,
+// scene constants.  Needs the mesh level of `sc` (build_mesh_level) and leaves it untouched.
+int build_top_level(rt_scene* sc, const rt_scene_desc* s) {
+    const rt_scene::MeshLevel& M = sc->mesh;
+    std::vector<DNode4> nodes;                   // the top level's records; record 0 of it is device record M.n_node_records
+    std::vector<DBigLeaf> big = M.big;
+
     // objects: meshes | spheres | triangles
     std::vector<DObject> objects(s->n_meshes + s->n_spheres + s->n_triangles);
     sc->ds.mesh_obj_base = 0;
@@ -319,7 +406,7 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
         const rt_mesh& m = s->meshes[i];
         DObject& o = objects[i];
         fill_object_common(o, m.flags, m.transform, m.inv_transform, m.motion_blur, m.material_id);
-        const BvhLayout& L = mesh_layout[m.bvh_index];
+        const MeshRoot& L = M.roots[m.bvh_index];
         o.root_link = L.root_link;
         o.rminx = L.rmin[0]; o.rminy = L.rmin[1]; o.rminz = L.rmin[2];
         o.rmaxx = L.rmax[0]; o.rmaxy = L.rmax[1]; o.rmaxz = L.rmax[2];
@@ -358,15 +445,11 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
         const rt_bvh_node& n = s->top_nodes[i];
         for (int32_t k = 0; k < n.prim_count; k++) top[n.left_or_first + k].remaining = (uint32_t)(n.prim_count - k);
     }
-    BvhLayout TL = layout_bvh(s->top_nodes, s->n_top_prims ? s->n_top_nodes : 0, 0, true, nodes, big);
-    if (nodes.size() >= 0x7FFFFFF0u || tris.size() >= RT_LEAF_MAX_FIRST || top.size() >= RT_LEAF_MAX_FIRST)
+    BvhLayout TL = layout_bvh(s->top_nodes, s->n_top_prims ? s->n_top_nodes : 0, 0, true, nodes, big, M.n_node_records);
+    if ((uint64_t)M.n_node_records + nodes.size() >= 0x7FFFFFF0u || top.size() >= RT_LEAF_MAX_FIRST)
         return fail(RT_ERR_UNSUPPORTED, "scene too large for the link encoding (2^26 leaf prims)");
     std::sort(big.begin(), big.end(), [](const DBigLeaf& a, const DBigLeaf& b) { return a.first < b.first; });
     if (big.empty()) big.push_back(DBigLeaf{0, 0});
-
-    std::vector<float4> vn(s->n_vertices);
-    for (uint32_t i = 0; i < s->n_vertices; i++)
-        vn[i] = make_float4(s->vertex_data[i].normal[0], s->vertex_data[i].normal[1], s->vertex_data[i].normal[2], 0.f);
 
     std::vector<DPlane> planes(s->n_planes);
     for (uint32_t i = 0; i < s->n_planes; i++) {
@@ -407,8 +490,10 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
 
     int rc;
     if ((rc = upload_vec(sc->b_area_lights, alights))) return rc;
-    if ((rc = upload_vec(sc->b_nodes, nodes)) || (rc = upload_vec(sc->b_tris, tris)) || (rc = upload_vec(sc->b_tri_shade, tshade)) ||
-        (rc = upload_vec(sc->b_vnormals, vn)) || (rc = upload_vec(sc->b_objects, objects)) || (rc = upload_vec(sc->b_top_prims, top)) ||
+    if ((rc = sc->b_nodes.grow_keep(((size_t)M.n_node_records + nodes.size()) * sizeof(DNode4), (size_t)M.n_node_records * sizeof(DNode4)))) return rc;
+    if (!nodes.empty())
+        HIPCHK(hipMemcpy((DNode4*)sc->b_nodes.p + M.n_node_records, nodes.data(), nodes.size() * sizeof(DNode4), hipMemcpyHostToDevice));
+    if ((rc = upload_vec(sc->b_objects, objects)) || (rc = upload_vec(sc->b_top_prims, top)) ||
         (rc = upload_vec(sc->b_big, big)) || (rc = upload_vec(sc->b_planes, planes)) || (rc = upload_vec(sc->b_materials, mats)) || (rc = upload_vec(sc->b_lights, lights)))
         return rc;
 
@@ -416,11 +501,8 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
     D.nodes = (const DNode4*)sc->b_nodes.p;
     D.big_leaves = (const DBigLeaf*)sc->b_big.p;
     D.n_big_leaves = (uint32_t)big.size();
-    D.donate_ok = donate_ok ? 1u : 0u;
+    D.donate_ok = M.donate_ok ? 1u : 0u;
     if (getenv("RT_NO_DONATE")) D.donate_ok = 0u;      // diagnostic: every ray is traced by its owner alone
-    D.tris = (const DTri*)sc->b_tris.p;
-    D.tri_shade = (const DTriShade*)sc->b_tri_shade.p;
-    D.vnormals = (const float4*)sc->b_vnormals.p;
     D.objects = (const DObject*)sc->b_objects.p;
     D.top_prims = (const DTopPrim*)sc->b_top_prims.p;
     D.planes = (const DPlane*)sc->b_planes.p;
@@ -436,8 +518,14 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
     std::memcpy(D.ambient, s->ambient_light, 12);
     D.shadow_eps = s->shadow_ray_epsilon;
     D.max_depth = s->max_recursion_depth;
+    if (sc->n_point_lights != s->n_point_lights) sc->pool.cap_records = 0;   // the shadow pool is sized by the light count
     sc->n_point_lights = s->n_point_lights;
     return RT_OK;
+}
+
+int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
+    int rc = build_mesh_level(sc, s);
+    return rc ? rc : build_top_level(sc, s);
 }
 
 int ensure_pool(rt_scene* sc) {
@@ -771,6 +859,21 @@ int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out) {
     sc->blocks_ordered = sc->n_cu * std::min(per_cu, cap);
     *out = sc;
     return RT_OK;
+}
+
+int rt_update_scene(rt_scene* sc, const rt_scene_desc* scene, uint32_t flags) {
+    if (!sc) return fail(RT_ERR_INVALID, "scene is NULL");
+    int rc = validate_scene(scene, false);
+    if (rc) return rc;
+    const rt_scene::MeshLevel& M = sc->mesh;
+    if (scene->n_mesh_bvhs != M.n_mesh_bvhs || scene->n_mesh_nodes != M.n_mesh_nodes || scene->n_mesh_prims != M.n_mesh_prims ||
+        scene->n_faces != M.n_faces || scene->n_vertices != M.n_vertices)
+        return fail(RT_ERR_INVALID, "rt_update_scene: the mesh arrays differ in size from the uploaded scene's; upload the scene instead");
+    if ((flags & RT_UPDATE_VERIFY_MESHES) && mesh_hash(scene) != M.hash)
+        return fail(RT_ERR_INVALID, "rt_update_scene: the mesh arrays differ from the uploaded scene's; upload the scene instead");
+    HIPCHK(hipSetDevice(sc->device));
+    HIPCHK(hipStreamSynchronize(sc->stream));      // no render of this scene may be in flight (the caller's stream: caller's duty)
+    return build_top_level(sc, scene);
 }
 
 int rt_scene_set_option(rt_scene* s, int option, uint64_t value) {

@@ -134,6 +134,7 @@
 struct TraceStatsAcc {
     unsigned long long wave_node_steps, lane_node_steps, wave_tri_steps, lane_tri_steps, wave_outer, lane_rays, wave_batches, wave_pops, lane_pops;
     unsigned int ray_leaves, ray_nodes;
+    unsigned long long tl_rounds, tl_sched, tl_node, tl_tri, tl_big, tl_trans;   // after the cursor was drained
     unsigned long long clk_start, r_node_w, r_node_l, r_tri_w, r_tri_l;   // activity histogram (flushed every round)
     unsigned long long t_sched, t_node, t_tri, t_big, t_trans, clk_exhausted, n_donations, n_coop, n_replays, n_elig, n_gate, n_casfail, n_claim, n_culled;
 };
@@ -144,12 +145,18 @@ struct TraceStatsAcc {
 #else
 #define RT_HIST_ANY false
 #endif
+#ifdef RT_RAY_HIST                 // per-ray work histogram (its same-address atomics distort every timing)
+#define RT_RAYHIST(x) x
+#else
+#define RT_RAYHIST(x)
+#endif
 #define RT_HIST_BINS 128
 #define RT_HIST_TICKS 2500ull     // 25 us per bin (wall_clock64 ticks are 10 ns)
 __device__ unsigned long long g_hist[RT_HIST_BINS][4];
 __device__ unsigned long long g_rayhist[2][20];   // [0]: rays by log2(leaves visited), [1]: by log2(node steps); owner lanes only
 #else
 #define RT_STAT(x)
+#define RT_RAYHIST(x)
 #define RT_CLK(v)
 #endif
 
@@ -524,7 +531,11 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             }
             // (c) a busy lane posts the bottom-most entry of its mesh-level stack while idle lanes outnumber posted tasks
             RT_STAT(if (alive && in_mesh && !no_donate && don_next < st.sp) { st.acc->n_elig++; if (!(st.blk[2] > st.blk[1])) st.acc->n_gate++; })
-            for (int pass = 0; pass < RT_DONATE_PASSES && alive && in_mesh && !no_donate && don_next < st.sp && st.blk[2] > st.blk[1]; pass++) {
+            for (int pass = 0; pass < RT_DONATE_PASSES && alive && in_mesh && !no_donate && don_next < st.sp && st.blk[2] > st.blk[1] && st.blk[1] < st.n_board; pass++) {
+#ifndef RT_DONATE_LEAVES
+                // a leaf is not worth a task: its few triangles cost less than handing it over
+                if (st.read_at(don_next).x & RT_LINK_LEAF) { don_next++; continue; }
+#endif
                 uint32_t* rec = st.board + (atomicAdd(&st.blk[3], 1u) % st.n_board) * 16u;
                 const bool got_slot = atomicCAS(&rec[0], 0u, 1u) == 0u;
                 RT_STAT(if (!got_slot) st.acc->n_casfail++;)
@@ -958,7 +969,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 atomicSub(&st.out_cnt[home], 1u);
             } else {
-                RT_STAT({ if (ANYHIT == RT_HIST_ANY) { atomicAdd(&g_rayhist[0][32 - __clz(st.acc->ray_leaves)], 1ull); atomicAdd(&g_rayhist[1][32 - __clz(st.acc->ray_nodes)], 1ull); } })
+                RT_RAYHIST({ if (ANYHIT == RT_HIST_ANY) { atomicAdd(&g_rayhist[0][32 - __clz(st.acc->ray_leaves)], 1ull); atomicAdd(&g_rayhist[1][32 - __clz(st.acc->ray_nodes)], 1ull); } })
                 io.store(item, ANYHIT ? fin : has, out, minT);
             }
             RT_STAT(st.acc->ray_leaves = 0; st.acc->ray_nodes = 0;)
@@ -1041,6 +1052,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                   if (st.acc->r_node_w) { atomicAdd(&g_hist[b][0], st.acc->r_node_w); atomicAdd(&g_hist[b][1], st.acc->r_node_l); }
                   if (st.acc->r_tri_w) { atomicAdd(&g_hist[b][2], st.acc->r_tri_w); atomicAdd(&g_hist[b][3], st.acc->r_tri_l); }
                   st.acc->r_node_w = st.acc->r_node_l = st.acc->r_tri_w = st.acc->r_tri_l = 0; })
+        RT_STAT({ if (exhausted) { const unsigned long long c5 = wall_clock64(); st.acc->tl_rounds++; st.acc->tl_sched += c1 - c0; st.acc->tl_node += c2 - c1; st.acc->tl_tri += c3 - c2; st.acc->tl_big += c4 - c3; st.acc->tl_trans += c5 - c4; } })
         RT_STAT({ const unsigned long long c5 = wall_clock64(); st.acc->t_sched += c1 - c0; st.acc->t_node += c2 - c1; st.acc->t_tri += c3 - c2; st.acc->t_big += c4 - c3; st.acc->t_trans += c5 - c4; })
     }
 }

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 RT_KIND_MESH, RT_KIND_TRIANGLE, RT_KIND_SPHERE, RT_KIND_PLANE = 0, 1, 2, 3
 RT_MAT_NONE, RT_MAT_MIRROR, RT_MAT_CONDUCTOR, RT_MAT_DIELECTRIC = 0, 1, 2, 3
 RT_FLAG_TIMING = 1
+RT_UPDATE_VERIFY_MESHES = 1
 RT_OPT_FLAGS, RT_OPT_POOL_RECORDS, RT_OPT_CHUNK_SAMPLES = 1, 2, 3
 
 
@@ -293,6 +294,7 @@ def hip_lib():
         L.rt_device_count.restype = C.c_int
         L.rt_upload_scene.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.rt_scene_set_option.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+        L.rt_update_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.rt_render_tile.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Stats)]
         L.rt_render_tile_device.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_int, C.c_int,
@@ -325,6 +327,10 @@ class DeviceScene:
 
     def set_option(self, option, value):
         _check(hip_lib().rt_scene_set_option(self._h, option, int(value)))
+
+    def update(self, host_scene, verify_meshes=False):
+        """rt_update_scene: next animation frame with the same meshes (transforms, lights, materials, top level change)."""
+        _check(hip_lib().rt_update_scene(self._h, host_scene.desc_ptr, RT_UPDATE_VERIFY_MESHES if verify_meshes else 0))
 
     def render(self, cam, x0=0, y0=0, w=None, h=None, want_hits=False, stats=None):
         """rt_render_tile into host numpy arrays.  Returns (rgb[h,w,3], hits[h,w,2] or None)."""

@@ -297,10 +297,13 @@ def mesh_scene(grid=709, width=1920, height=1080, num_samples=1, name=None, tess
     return s
 
 
-def instanced_scene(grid=709, width=1920, height=1080, num_samples=1, max_depth=6, name=None):
+def instanced_scene(grid=709, width=1920, height=1080, num_samples=1, max_depth=6, name=None, frame=0):
     """M3/M5: the displaced sphere plus 9 MeshInstances (translations, rotations,
     non-uniform and one negative-determinant scaling) with diffuse, mirror,
-    conductor and dielectric materials, depth 6."""
+    conductor and dielectric materials, depth 6.
+    frame > 0: a later frame of an animation of the same meshes: the instances turn and move,
+    a light and the camera move, a material changes; from frame 2 on a sphere joins the top level; frame 3
+    makes the mirror rough (the frame then needs the depth-first pixel loop)."""
     s = SynthScene(name or f"inst10_{grid}")
     s.max_depth = max_depth
     s.ambient = (20, 20, 20)
@@ -331,6 +334,17 @@ def instanced_scene(grid=709, width=1920, height=1080, num_samples=1, max_depth=
         s.instances.append(dict(base=1, material=mats[k], transform=[("s", sc), ("r", (ang,) + axis), ("t", pos)], reset=False))
     s.camera = dict(position=(0.5, 2.4, 7.5), gaze_point=(0, 0.0, -2.0), up=(0, 1, 0), fovy=40.0, near=1.0, width=width,
                     height=height, num_samples=num_samples)
+    if frame:
+        for k, inst in enumerate(s.instances):
+            inst["transform"] = inst["transform"] + [("r", (9.0 * frame + k, 0.0, 1.0, 0.0)), ("t", (0.1 * frame, 0.05 * frame * (k % 3), 0.0))]
+        s.point_lights[0] = ((6.0 - frame, 9.0, 8.0 + 0.5 * frame), (160000, 160000, 160000))
+        s.materials[0]["diffuse"] = (0.8 - 0.1 * frame, 0.7, 0.5 + 0.1 * frame)
+        s.camera["position"] = (0.5 + 0.4 * frame, 2.4, 7.5 - 0.2 * frame)
+        if frame >= 2:
+            s.spheres.append(dict(center=1, radius=0.6, material=3, transform=[("t", (14.5, 1.8, 12.0))]))
+        if frame >= 3:
+            s.materials[2]["roughness"] = 0.15
+        s.name += f"_f{frame}"
     return s
 
 

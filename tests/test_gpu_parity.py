@@ -206,3 +206,35 @@ def test_errors_are_reported_not_thrown(rt):
         ds2.render(cam, x0=700, y0=0, w=200, h=10)         # outside the image
     ds.close()
     ds2.close()
+
+
+@pytest.mark.gpu
+def test_update_scene_keeps_meshes_and_equals_oracle(rt):
+    """rt_update_scene: frames of an animation over the same meshes.  Each frame rendered from the
+    updated scene must be what the oracle renders for that frame's description (transforms, lights, material,
+    camera change; frame 2 adds a top-level sphere; frame 3 needs the depth-first pixel loop)."""
+    from oracle import binding as ob
+    from raytracer_amd import scenes
+    a = scenes.instanced_scene(grid=40, width=192, height=108).build()
+    ds = rt.DeviceScene(a, 0)
+    for frame in (0, 1, 2, 3, 1):
+        hs = a if frame == 0 else scenes.instanced_scene(grid=40, width=192, height=108, frame=frame).build()
+        if frame:
+            ds.update(hs, verify_meshes=True)
+        cam = hs.camera(0)
+        rgb, hits = ds.render(cam, want_hits=True)
+        o_rgb, o_hits, _ = ob.render(hs, cam, want_hits=True)
+        assert (hits == o_hits).all(), frame
+        assert (rgb == o_rgb).all(), frame
+    # other meshes: refused (sizes), and with the same sizes by the hash
+    with pytest.raises(rt.RtError):
+        ds.update(scenes.instanced_scene(grid=41, width=192, height=108).build())
+    spec = scenes.instanced_scene(grid=40, width=192, height=108)
+    spec.meshes[1]["verts"] = spec.meshes[1]["verts"] * np.float32(1.5)
+    with pytest.raises(rt.RtError):
+        ds.update(spec.build(), verify_meshes=True)
+    # the scene is still the last good frame
+    hs = scenes.instanced_scene(grid=40, width=192, height=108, frame=1).build()
+    rgb, _ = ds.render(hs.camera(0))
+    assert (rgb == ob.render(hs, hs.camera(0))[0]).all()
+    ds.close()
