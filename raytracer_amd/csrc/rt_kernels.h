@@ -349,8 +349,8 @@ __device__ void report_trace_stats(Control* ctl, const TraceStatsAcc& acc, unsig
         }
     }
     atomicAdd(&ctl->dbg[6], acc.n_elig); atomicAdd(&ctl->dbg[7], acc.n_gate); atomicAdd(&ctl->dbg[8], acc.n_casfail); atomicAdd(&ctl->dbg[9], acc.n_claim);
-    if (ww.lane == 0 && (blockIdx.x % 37) == 0 && ww.wave < 16) printf("[tail] block %d wave %u: life %.0f exhausted@%.0f | tail rounds %llu sched %.0f node %.0f tri %.0f big %.0f trans %.0f us\n", (int)blockIdx.x, ww.wave,
-        (wall_clock64() - clk_start) * 0.01, acc.clk_exhausted ? (acc.clk_exhausted - clk_start) * 0.01 : 0.0, acc.tl_rounds, acc.tl_sched * 0.01, acc.tl_node * 0.01, acc.tl_tri * 0.01, acc.tl_big * 0.01, acc.tl_trans * 0.01);
+    if (ww.lane == 0 && (blockIdx.x % 37) == 0 && ww.wave < 16) printf("[tail] block %d wave %u: life %.0f exhausted@%.0f | tail rounds %llu sched %.0f (claim %.0f announce %.0f post %.0f [%llu iters] rest %.0f) node %.0f tri %.0f big %.0f trans %.0f us\n", (int)blockIdx.x, ww.wave,
+        (wall_clock64() - clk_start) * 0.01, acc.clk_exhausted ? (acc.clk_exhausted - clk_start) * 0.01 : 0.0, acc.tl_rounds, acc.tl_sched * 0.01, acc.ts_a * 0.01, acc.ts_b * 0.01, acc.ts_c * 0.01, acc.ts_post_iters, acc.ts_d * 0.01, acc.tl_node * 0.01, acc.tl_tri * 0.01, acc.tl_big * 0.01, acc.tl_trans * 0.01);
     if (ww.lane == 0 && blockIdx.x == 0) printf("[board] block 0 wave %u: busy %u ready %u idle %u postcur %u\n", ww.wave, st.blk[0], st.blk[1], st.blk[2], st.blk[3]);
     {   // step counts live in whichever lane was first active: sum them per wave (after lane 0's plain stores above)
         __threadfence();

@@ -124,7 +124,10 @@ struct OrderedArgs {
     const DTriShade* tri_shade;
 };
 
-__global__ void __launch_bounds__(RT_ORDERED_BLOCK, 2) k_pixel_ordered(DScene S, OrderedArgs A, Control* ctl, uint2* spill, uint4* cand) {
+#ifndef RT_ORDERED_MIN_BLOCKS
+#define RT_ORDERED_MIN_BLOCKS 3  // workgroups per CU the register budget is set for
+#endif
+__global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pixel_ordered(DScene S, OrderedArgs A, Control* ctl, uint2* spill, uint4* cand) {
     __shared__ TraceLds<RT_ORDERED_BLOCK> s_lds;
     uint32_t* s_cursor = s_lds.cursor;
     WaveWork ww;

@@ -134,6 +134,7 @@
 struct TraceStatsAcc {
     unsigned long long wave_node_steps, lane_node_steps, wave_tri_steps, lane_tri_steps, wave_outer, lane_rays, wave_batches, wave_pops, lane_pops;
     unsigned int ray_leaves, ray_nodes;
+    unsigned long long ts_a, ts_b, ts_c, ts_d, ts_post_iters;   // tail: parts of the scheduling section
     unsigned long long tl_rounds, tl_sched, tl_node, tl_tri, tl_big, tl_trans;   // after the cursor was drained
     unsigned long long clk_start, r_node_w, r_node_l, r_tri_w, r_tri_l;   // activity histogram (flushed every round)
     unsigned long long t_sched, t_node, t_tri, t_big, t_trans, clk_exhausted, n_donations, n_coop, n_replays, n_elig, n_gate, n_casfail, n_claim, n_culled;
@@ -445,6 +446,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
     uint32_t cur = RT_LINK_DONE;
     float cur_t = 0.f;           // box entry distance of `cur`
     uint32_t don_next = 0;       // stack slot of the bottom-most mesh-level entry not yet given away
+    uint32_t don_base = 0;       // stack slot above the sentinel of the mesh traversal in flight
     bool donated = false;        // owner: subtrees of the mesh traversal in flight were given away
     bool no_donate = false;      // owner: re-traversing alone after a candidate overflow
     bool exhausted = false;      // wave-uniform: the cursor has passed the last item
@@ -490,6 +492,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             break;
         }
         if (split_now) {
+            RT_CLK(s0);
             // (a) an idle lane takes a posted subtree
             if (!alive && st.blk[1] != 0) {
                 const uint32_t start = (lane * 7u + st.slot + round) % st.n_board;
@@ -518,9 +521,11 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                         st.sp = 0;
                         st.push(RT_LINK_SENTINEL, -1.0f);
                         don_next = st.sp;
+                        don_base = st.sp;
                     }
                 }
             }
+            RT_CLK(s1);
             // (b) the wave tells the workgroup how many of its lanes are idle
             {
                 const uint32_t n_idle_now = (uint32_t)__popcll(__ballot(!alive));
@@ -529,13 +534,11 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     idle_posted = n_idle_now;
                 }
             }
+            RT_CLK(s2);
             // (c) a busy lane posts the bottom-most entry of its mesh-level stack while idle lanes outnumber posted tasks
             RT_STAT(if (alive && in_mesh && !no_donate && don_next < st.sp) { st.acc->n_elig++; if (!(st.blk[2] > st.blk[1])) st.acc->n_gate++; })
             for (int pass = 0; pass < RT_DONATE_PASSES && alive && in_mesh && !no_donate && don_next < st.sp && st.blk[2] > st.blk[1] && st.blk[1] < st.n_board; pass++) {
-#ifndef RT_DONATE_LEAVES
-                // a leaf is not worth a task: its few triangles cost less than handing it over
-                if (st.read_at(don_next).x & RT_LINK_LEAF) { don_next++; continue; }
-#endif
+                RT_STAT(if (st.lane == __ffsll((long long)__ballot(1)) - 1) st.acc->ts_post_iters++;)
                 uint32_t* rec = st.board + (atomicAdd(&st.blk[3], 1u) % st.n_board) * 16u;
                 const bool got_slot = atomicCAS(&rec[0], 0u, 1u) == 0u;
                 RT_STAT(if (!got_slot) st.acc->n_casfail++;)
@@ -566,6 +569,15 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     }
                 }
             }
+            RT_CLK(s3);
+            // The slots given away are the bottom of the mesh-level stack: close the gap (usually nothing is left
+            // above it), so that the stack stays short and in LDS instead of growing into its global part.
+            if (alive && in_mesh && don_next > don_base) {
+                const uint32_t gap = don_next - don_base;
+                for (uint32_t pos = don_next; pos < st.sp; pos++) st.write_at(pos - gap, st.read_at(pos));
+                st.sp -= gap;
+                don_next = don_base;
+            }
             // (d) any-hit found by somebody working on the same ray: helpers drop their subtree, the owner stops
             //     its own part (pops down to the sentinel) and finishes once its helpers are gone
             if (ANYHIT && alive && (helper || donated) && st.cancel[home] != 0) {
@@ -577,6 +589,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     cur = st.pop(-1.0f, cur_t);              // everything above the sentinel is culled by a negative bound
                 }
             }
+            RT_STAT({ const unsigned long long s4 = wall_clock64(); if (__any(alive)) { st.acc->ts_a += s1 - s0; st.acc->ts_b += s2 - s1; st.acc->ts_c += s3 - s2; st.acc->ts_d += s4 - s3; } })
         }
 
         // ---- nothing to do in this wave: leave, or stay to help the workgroup
@@ -920,6 +933,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     in_mesh = true;
                     st.push(RT_LINK_SENTINEL, -1.0f);
                     don_next = st.sp;
+                        don_base = st.sp;
                     donated = false;
                     cur = ob.root_link;
                     cur_t = te;
