@@ -33,7 +33,9 @@
 // record: for a reference interior node n with children L, R the four slots are
 // L.left, L.right, R.left, R.right in that (= the reference's depth-first)
 // order; a child that is itself a leaf occupies its first slot and leaves the
-// second one empty (mask bit clear).  box k = f[6k .. 6k+5] = min.xyz, max.xyz.
+// second one empty (mask bit clear).  Planes by axis: f[0..3] = min.x of the four slots, f[4..7] = max.x,
+// f[8..11] = min.y, f[12..15] = max.y, f[16..19] = min.z, f[20..23] = max.z, so that a lane fetches the four
+// planes its ray meets first on an axis with one 16-byte load picked by the sign of 1/d.
 struct __attribute__((aligned(128))) DNode4 {
     float    f[24];
     uint32_t link[4];

@@ -232,8 +232,8 @@ struct BvhBuilder4 {
             int s = 0;
             auto put = [&](int slot, uint32_t ref) {
                 const rt_bvh_node& c = nodes[ref];
-                float* f = d.f + 6 * slot;
-                f[0] = c.bmin[0]; f[1] = c.bmin[1]; f[2] = c.bmin[2]; f[3] = c.bmax[0]; f[4] = c.bmax[1]; f[5] = c.bmax[2];
+                float* f = d.f + slot;          // planes by axis (rt_device.h)
+                f[0] = c.bmin[0]; f[4] = c.bmax[0]; f[8] = c.bmin[1]; f[12] = c.bmax[1]; f[16] = c.bmin[2]; f[20] = c.bmax[2];
                 d.mask |= 1u << slot;
                 if (c.prim_count > 0) {
                     d.link[slot] = leaf_link(c);

@@ -260,6 +260,53 @@ __device__ __forceinline__ bool box_test(const ActiveRay& r, float mnx, float mn
     return (tMin <= tMax) && (tMax > 0.0f);
 }
 
+// The same test for the four slots of a node record at once.  n* / f* hold, per axis, the planes of the four
+// slots the ray meets first / last when they are picked by the sign of 1/d: with a = (near - o)/d's stand-in
+// (near - o) * inv and b = (far - o) * inv, the reference's t0,t1 are (a,b) for inv >= 0 and (b,a) for inv < 0,
+// and its swap `if (t1 < t0)` then yields lo = a, hi = b: for finite inv because FP32 subtraction and
+// multiplication are monotone (equal values may stay unswapped in the reference, which changes nothing); for
+// inv = +inf (d == 0 here, or 1/d overflowing) because a NaN never swaps and no other pair is out of order.
+// Only inv = -inf (a negative d below 2^-128) can pair a NaN with an unswapped order that differs; lanes with
+// such a ray redo the reference's compare-and-swap on the same two products (`odd` below).  The two products per
+// axis are packed FP32 operations on slot pairs (IEEE per component); min/max chains as in box_test.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void slab_pair(float p0, float p1, float o, float inv, float& r0, float& r1) {
+    const v2f oo = {o, o}, ii = {inv, inv}, pp = {p0, p1};
+    const v2f r = (pp - oo) * ii;
+    r0 = r.x;
+    r1 = r.y;
+}
+__device__ __forceinline__ void node_slabs4(const ActiveRay& r, float4 nx, float4 fx, float4 ny, float4 fy, float4 nz, float4 fz,
+                                            bool sx, bool sy, bool sz, float tmax, float te[4], bool hit[4]) {
+    float ax[4], bx[4], ay[4], by[4], az[4], bz[4];
+    slab_pair(nx.x, nx.y, r.ox, r.ix, ax[0], ax[1]); slab_pair(nx.z, nx.w, r.ox, r.ix, ax[2], ax[3]);
+    slab_pair(fx.x, fx.y, r.ox, r.ix, bx[0], bx[1]); slab_pair(fx.z, fx.w, r.ox, r.ix, bx[2], bx[3]);
+    slab_pair(ny.x, ny.y, r.oy, r.iy, ay[0], ay[1]); slab_pair(ny.z, ny.w, r.oy, r.iy, ay[2], ay[3]);
+    slab_pair(fy.x, fy.y, r.oy, r.iy, by[0], by[1]); slab_pair(fy.z, fy.w, r.oy, r.iy, by[2], by[3]);
+    slab_pair(nz.x, nz.y, r.oz, r.iz, az[0], az[1]); slab_pair(nz.z, nz.w, r.oz, r.iz, az[2], az[3]);
+    slab_pair(fz.x, fz.y, r.oz, r.iz, bz[0], bz[1]); slab_pair(fz.z, fz.w, r.oz, r.iz, bz[2], bz[3]);
+    const bool odd = fminf(fminf(r.ix, r.iy), r.iz) == -RT_INF;
+    if (__any(odd)) {
+        if (odd) {
+            auto redo = [](float& a, float& b, bool s) {       // t0,t1 as the reference has them, then its swap
+                const float t0 = s ? b : a, t1 = s ? a : b;
+                const bool sw = t1 < t0;
+                a = sw ? t1 : t0;
+                b = sw ? t0 : t1;
+            };
+#pragma unroll
+            for (int k = 0; k < 4; k++) { redo(ax[k], bx[k], sx); redo(ay[k], by[k], sy); redo(az[k], bz[k], sz); }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float tMin = fmaxf(fmaxf(fmaxf(0.0f, ax[k]), ay[k]), az[k]);
+        const float tMax = fminf(fminf(fminf(tmax, bx[k]), by[k]), bz[k]);
+        te[k] = tMin;
+        hit[k] = (tMin <= tMax) && (tMax > 0.0f);
+    }
+}
+
 // IntersectsTriangle_Bary, raytracer.cpp:896-947, with col_A0/col_A1 preloaded.
 // Straight-line form: the reference's early returns become one verdict (each
 // condition is evaluated on the same values in the same order; a quotient by a
@@ -640,15 +687,30 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 if (!(cur & RT_LINK_LEAF)) {
                     RT_STAT(st.acc->ray_nodes++;)
                     RT_STAT({ unsigned long long m = __ballot(1); if (st.lane == __ffsll((long long)m) - 1) { st.acc->wave_node_steps++; st.acc->lane_node_steps += __popcll(m); st.acc->r_node_w++; st.acc->r_node_l += __popcll(m); } })
-                    const float4* p = reinterpret_cast<const float4*>(&S.nodes[cur]);
-                    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
-                    const uint4 lk = reinterpret_cast<const uint4*>(p)[6];
-                    float t0, t1, t2, t3;
+                    // The record holds, per axis, the four slots' min planes and their max planes (rt_device.h).  A
+                    // lane reads per axis the planes its ray meets first and the ones it meets last — min then max
+                    // if 1/d >= 0 (+inf for d == 0 included), max then min otherwise — so the slab distances come
+                    // out ordered without the reference's compare-and-swap (node_slabs4).
+                    const char* nodes_b = reinterpret_cast<const char*>(S.nodes);
+                    const uint64_t no = (uint64_t)cur << 7;
+                    const char* nb = nodes_b + no;
+                    const uint32_t sx = (__float_as_uint(ar.ix) >> 31) << 4, sy = (__float_as_uint(ar.iy) >> 31) << 4,
+                                   sz = (__float_as_uint(ar.iz) >> 31) << 4;
+                    // (records are 128-byte aligned: the other 16-byte half of an axis' 32 bytes is the offset ^ 16)
+                    const uint64_t ox_ = no + sx, oy_ = no + sy, oz_ = no + sz;
+                    const float4 nx = *reinterpret_cast<const float4*>(nodes_b + ox_), fx = *reinterpret_cast<const float4*>(nodes_b + (ox_ ^ 16u));
+                    const float4 ny = *reinterpret_cast<const float4*>(nodes_b + oy_ + 32u), fy = *reinterpret_cast<const float4*>(nodes_b + (oy_ ^ 16u) + 32u);
+                    const float4 nz = *reinterpret_cast<const float4*>(nodes_b + oz_ + 64u), fz = *reinterpret_cast<const float4*>(nodes_b + (oz_ ^ 16u) + 64u);
+                    const uint4 lk = *reinterpret_cast<const uint4*>(nb + 96u);
+                    float te4[4];
+                    bool hit4[4];
+                    node_slabs4(ar, nx, fx, ny, fy, nz, fz, sx != 0u, sy != 0u, sz != 0u, tmax, te4, hit4);
+                    const float t0 = te4[0], t1 = te4[1], t2 = te4[2], t3 = te4[3];
                     // slot 0 is always valid; an empty slot carries RT_LINK_DONE
-                    const bool h0 = box_test(ar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax, t0);
-                    const bool h1 = box_test(ar, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax, t1) & (lk.y != RT_LINK_DONE);
-                    const bool h2 = box_test(ar, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, tmax, t2) & (lk.z != RT_LINK_DONE);
-                    const bool h3 = box_test(ar, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, tmax, t3) & (lk.w != RT_LINK_DONE);
+                    const bool h0 = hit4[0];
+                    const bool h1 = hit4[1] & (lk.y != RT_LINK_DONE);
+                    const bool h2 = hit4[2] & (lk.z != RT_LINK_DONE);
+                    const bool h3 = hit4[3] & (lk.w != RT_LINK_DONE);
                     // visit order = slot order: the first hit slot is next, the later ones are
                     // pushed last-first so that they pop in order
                     const bool p1 = h1 & h0, p2 = h2 & (h0 | h1), p3 = h3 & (h0 | h1 | h2);
