@@ -1,0 +1,134 @@
+// rt_box.h — the ray/box arithmetic of the traversal (IntersectAABB, raytracer.cpp:815-894), kept free of
+// HIP-only constructs so that tests/box_logic.cpp can compile the very same text for the host and compare
+// it with the oracle's restatement of the reference over adversarial operands (zero and denormal direction
+// components, origins on box planes, degenerate boxes, infinities).  Device builds include it through
+// rt_traverse.h; the host test defines RT_BOX_HOST and supplies V3 / float4 / RT_INF itself.
+#pragma once
+#ifdef RT_BOX_HOST
+#define RT_BOX_FN static inline
+#define RT_BOX_MEMFN inline
+#define RT_BOX_ANY(x) (x)
+#else
+#define RT_BOX_FN __device__ __forceinline__
+#define RT_BOX_MEMFN __device__ __forceinline__
+#define RT_BOX_ANY(x) __any(x)
+#endif
+
+// The ray a lane is currently traversing with (world or object space).
+struct ActiveRay {
+    float ox, oy, oz, dx, dy, dz;
+    float ix, iy, iz;     // 1.0f / d (IEEE); +inf where d == 0 (such rays, and those whose 1/d overflows, take box_literal)
+    RT_BOX_MEMFN void set(V3 o, V3 d) {
+        ox = o.x; oy = o.y; oz = o.z; dx = d.x; dy = d.y; dz = d.z;
+        ix = (d.x == 0.0f) ? RT_INF : 1.0f / d.x;
+        iy = (d.y == 0.0f) ? RT_INF : 1.0f / d.y;
+        iz = (d.z == 0.0f) ? RT_INF : 1.0f / d.z;
+    }
+};
+
+// IntersectAABB (raytracer.cpp:815-894), literally: the path of rays with an infinite 1/d on some axis (d == 0,
+// or a d so small that 1/d overflows).  The reference treats d == 0 by an inside test that does not depend on
+// minT, and 1/d = +-inf produces NaN products on box planes through the origin, whose fate depends on the
+// unswapped order — neither is reproduced by the ordered-slab arithmetic below once minT itself is infinite
+// (testMinT = minT * scale overflows for a scaled instance, raytracer.cpp:579) or 1/d is -inf.  The early returns
+// become a flag: later axes only touch values that are no longer looked at.  tEnter = the reference's tMin.
+RT_BOX_FN bool box_literal(const ActiveRay& r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float minT,
+                           float& tEnter) {
+    float tMin = 0.0f, tMax = minT;
+    bool miss = false;
+    auto axis = [&](float d, float inv, float o, float mn, float mx) {
+        if (d != 0.0f) {
+            float t0 = (mn - o) * inv, t1 = (mx - o) * inv;
+            if (t1 < t0) { const float t = t0; t0 = t1; t1 = t; }
+            tMin = (tMin < t0) ? t0 : tMin;     // std::max(tMin, t0)
+            tMax = (t1 < tMax) ? t1 : tMax;     // std::min(tMax, t1)
+            if (tMax < tMin) miss = true;
+        } else if (o < mn || o > mx) {
+            miss = true;
+        }
+    };
+    axis(r.dx, r.ix, r.ox, mnx, mxx);
+    axis(r.dy, r.iy, r.oy, mny, mxy);
+    axis(r.dz, r.iz, r.oz, mnz, mxz);
+    tEnter = tMin;
+    if (miss) return false;
+    float tHit = tMin;
+    if (!(tMin > 0.0f)) {
+        if (tMax <= 0.0f) return false;
+        tHit = tMax;
+    }
+    return !(tHit > minT);
+}
+RT_BOX_FN bool ray_is_odd(const ActiveRay& r) {     // some 1/d is infinite
+    return fmaxf(fmaxf(fabsf(r.ix), fabsf(r.iy)), fabsf(r.iz)) == RT_INF;
+}
+
+// The same verdict + entry distance, branch-free, for rays whose three 1/d are finite: no product is a NaN
+// then, so per axis lo = min(t0,t1), hi = max(t0,t1) as the reference's swap leaves them; tMin = max(0, lo...),
+// tMax = min(minT, hi...); the per-axis early returns equal one final test because tMin only grows and tMax
+// only shrinks; "hit" = !(tMax < tMin) && !(tMin == 0 && tMax <= 0) = (tMin <= tMax) && (tMax > 0); the
+// trailing `tHit > minT` test (raytracer.cpp:889) cannot fire once tMax <= minT.
+RT_BOX_FN bool box_test(const ActiveRay& r, float mnx, float mny, float mnz, float mxx, float mxy,
+                                         float mxz, float tmax, float& tEnter) {
+    if (ray_is_odd(r)) return box_literal(r, mnx, mny, mnz, mxx, mxy, mxz, tmax, tEnter);
+    const float ax = (mnx - r.ox) * r.ix, bx = (mxx - r.ox) * r.ix;
+    const float ay = (mny - r.oy) * r.iy, by = (mxy - r.oy) * r.iy;
+    const float az = (mnz - r.oz) * r.iz, bz = (mxz - r.oz) * r.iz;
+    const bool sx = bx < ax, sy = by < ay, sz = bz < az;
+    const float lox = sx ? bx : ax, hix = sx ? ax : bx;
+    const float loy = sy ? by : ay, hiy = sy ? ay : by;
+    const float loz = sz ? bz : az, hiz = sz ? az : bz;
+    const float tMin = fmaxf(fmaxf(fmaxf(0.0f, lox), loy), loz);
+    const float tMax = fminf(fminf(fminf(tmax, hix), hiy), hiz);
+    tEnter = tMin;
+    return (tMin <= tMax) && (tMax > 0.0f);
+}
+
+// The same test for the four slots of a node record at once.  n* / f* hold, per axis, the planes of the four
+// slots the ray meets first / last when they are picked by the sign of 1/d (min then max for 1/d >= 0): with
+// a = (near - o) * inv and b = (far - o) * inv the reference's t0,t1 are (a,b) or (b,a), and since FP32
+// subtraction and multiplication by a finite inv are monotone, a <= b: its swap leaves lo = a, hi = b (equal
+// values may stay unswapped there, which changes nothing).  Lanes whose ray has an infinite 1/d take
+// box_literal on the same planes instead.  The two products per axis are packed FP32 operations on slot pairs
+// (IEEE per component); min/max chains as in box_test.
+typedef float v2f __attribute__((ext_vector_type(2)));
+RT_BOX_FN void slab_pair(float p0, float p1, float o, float inv, float& r0, float& r1) {
+    const v2f oo = {o, o}, ii = {inv, inv}, pp = {p0, p1};
+    const v2f r = (pp - oo) * ii;
+    r0 = r.x;
+    r1 = r.y;
+}
+// (fast form: the caller has made sure that no lane taking part has an infinite 1/d)
+RT_BOX_FN void node_slabs4(const ActiveRay& r, float4 nx, float4 fx, float4 ny, float4 fy, float4 nz, float4 fz,
+                           float tmax, float te[4], bool hit[4]) {
+    float ax[4], bx[4], ay[4], by[4], az[4], bz[4];
+    slab_pair(nx.x, nx.y, r.ox, r.ix, ax[0], ax[1]); slab_pair(nx.z, nx.w, r.ox, r.ix, ax[2], ax[3]);
+    slab_pair(fx.x, fx.y, r.ox, r.ix, bx[0], bx[1]); slab_pair(fx.z, fx.w, r.ox, r.ix, bx[2], bx[3]);
+    slab_pair(ny.x, ny.y, r.oy, r.iy, ay[0], ay[1]); slab_pair(ny.z, ny.w, r.oy, r.iy, ay[2], ay[3]);
+    slab_pair(fy.x, fy.y, r.oy, r.iy, by[0], by[1]); slab_pair(fy.z, fy.w, r.oy, r.iy, by[2], by[3]);
+    slab_pair(nz.x, nz.y, r.oz, r.iz, az[0], az[1]); slab_pair(nz.z, nz.w, r.oz, r.iz, az[2], az[3]);
+    slab_pair(fz.x, fz.y, r.oz, r.iz, bz[0], bz[1]); slab_pair(fz.z, fz.w, r.oz, r.iz, bz[2], bz[3]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float tMin = fmaxf(fmaxf(fmaxf(0.0f, ax[k]), ay[k]), az[k]);
+        const float tMax = fminf(fminf(fminf(tmax, bx[k]), by[k]), bz[k]);
+        te[k] = tMin;
+        hit[k] = (tMin <= tMax) && (tMax > 0.0f);
+    }
+}
+// (general form: lanes with an infinite 1/d take box_literal on the same planes; sx/sy/sz = the plane order picked)
+RT_BOX_FN void node_slabs4_any(const ActiveRay& r, float4 nx, float4 fx, float4 ny, float4 fy, float4 nz, float4 fz,
+                               bool sx, bool sy, bool sz, float tmax, float te[4], bool hit[4]) {
+    if (ray_is_odd(r)) {
+        const float nxa[4] = {nx.x, nx.y, nx.z, nx.w}, fxa[4] = {fx.x, fx.y, fx.z, fx.w};
+        const float nya[4] = {ny.x, ny.y, ny.z, ny.w}, fya[4] = {fy.x, fy.y, fy.z, fy.w};
+        const float nza[4] = {nz.x, nz.y, nz.z, nz.w}, fza[4] = {fz.x, fz.y, fz.z, fz.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            hit[k] = box_literal(r, sx ? fxa[k] : nxa[k], sy ? fya[k] : nya[k], sz ? fza[k] : nza[k],
+                                 sx ? nxa[k] : fxa[k], sy ? nya[k] : fya[k], sz ? nza[k] : fza[k], tmax, te[k]);
+    } else {
+        node_slabs4(r, nx, fx, ny, fy, nz, fz, tmax, te, hit);
+    }
+}
+

@@ -225,87 +225,7 @@ struct TraceStack {
     }
 };
 
-// The ray a lane is currently traversing with (world or object space).
-struct ActiveRay {
-    float ox, oy, oz, dx, dy, dz;
-    float ix, iy, iz;     // 1.0f / d (IEEE); +inf where d == 0 (see file header)
-    __device__ __forceinline__ void set(V3 o, V3 d) {
-        ox = o.x; oy = o.y; oz = o.z; dx = d.x; dy = d.y; dz = d.z;
-        ix = (d.x == 0.0f) ? RT_INF : 1.0f / d.x;
-        iy = (d.y == 0.0f) ? RT_INF : 1.0f / d.y;
-        iz = (d.z == 0.0f) ? RT_INF : 1.0f / d.z;
-    }
-};
-
-// IntersectAABB (raytracer.cpp:815-894) verdict + entry distance, branch-free.
-// Per axis: t0,t1, swapped iff t1 < t0 (as the reference's explicit swap: a NaN
-// never swaps); tMin = std::max(tMin, lo), tMax = std::min(tMax, hi) keep their
-// first argument when the second is NaN, which is what fmaxf/fminf (v_max_f32 /
-// v_min_f32) do since tMin/tMax themselves are never NaN.  The per-axis early
-// returns equal one final test because tMin only grows and tMax only shrinks;
-// "hit" = !(tMax < tMin) && !(tMin == 0 && tMax <= 0) = (tMin <= tMax) && (tMax > 0);
-// the trailing `tHit > minT` test (raytracer.cpp:889) cannot fire once tMax <= minT.
-__device__ __forceinline__ bool box_test(const ActiveRay& r, float mnx, float mny, float mnz, float mxx, float mxy,
-                                         float mxz, float tmax, float& tEnter) {
-    const float ax = (mnx - r.ox) * r.ix, bx = (mxx - r.ox) * r.ix;
-    const float ay = (mny - r.oy) * r.iy, by = (mxy - r.oy) * r.iy;
-    const float az = (mnz - r.oz) * r.iz, bz = (mxz - r.oz) * r.iz;
-    const bool sx = bx < ax, sy = by < ay, sz = bz < az;
-    const float lox = sx ? bx : ax, hix = sx ? ax : bx;
-    const float loy = sy ? by : ay, hiy = sy ? ay : by;
-    const float loz = sz ? bz : az, hiz = sz ? az : bz;
-    const float tMin = fmaxf(fmaxf(fmaxf(0.0f, lox), loy), loz);
-    const float tMax = fminf(fminf(fminf(tmax, hix), hiy), hiz);
-    tEnter = tMin;
-    return (tMin <= tMax) && (tMax > 0.0f);
-}
-
-// The same test for the four slots of a node record at once.  n* / f* hold, per axis, the planes of the four
-// slots the ray meets first / last when they are picked by the sign of 1/d: with a = (near - o)/d's stand-in
-// (near - o) * inv and b = (far - o) * inv, the reference's t0,t1 are (a,b) for inv >= 0 and (b,a) for inv < 0,
-// and its swap `if (t1 < t0)` then yields lo = a, hi = b: for finite inv because FP32 subtraction and
-// multiplication are monotone (equal values may stay unswapped in the reference, which changes nothing); for
-// inv = +inf (d == 0 here, or 1/d overflowing) because a NaN never swaps and no other pair is out of order.
-// Only inv = -inf (a negative d below 2^-128) can pair a NaN with an unswapped order that differs; lanes with
-// such a ray redo the reference's compare-and-swap on the same two products (`odd` below).  The two products per
-// axis are packed FP32 operations on slot pairs (IEEE per component); min/max chains as in box_test.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void slab_pair(float p0, float p1, float o, float inv, float& r0, float& r1) {
-    const v2f oo = {o, o}, ii = {inv, inv}, pp = {p0, p1};
-    const v2f r = (pp - oo) * ii;
-    r0 = r.x;
-    r1 = r.y;
-}
-__device__ __forceinline__ void node_slabs4(const ActiveRay& r, float4 nx, float4 fx, float4 ny, float4 fy, float4 nz, float4 fz,
-                                            bool sx, bool sy, bool sz, float tmax, float te[4], bool hit[4]) {
-    float ax[4], bx[4], ay[4], by[4], az[4], bz[4];
-    slab_pair(nx.x, nx.y, r.ox, r.ix, ax[0], ax[1]); slab_pair(nx.z, nx.w, r.ox, r.ix, ax[2], ax[3]);
-    slab_pair(fx.x, fx.y, r.ox, r.ix, bx[0], bx[1]); slab_pair(fx.z, fx.w, r.ox, r.ix, bx[2], bx[3]);
-    slab_pair(ny.x, ny.y, r.oy, r.iy, ay[0], ay[1]); slab_pair(ny.z, ny.w, r.oy, r.iy, ay[2], ay[3]);
-    slab_pair(fy.x, fy.y, r.oy, r.iy, by[0], by[1]); slab_pair(fy.z, fy.w, r.oy, r.iy, by[2], by[3]);
-    slab_pair(nz.x, nz.y, r.oz, r.iz, az[0], az[1]); slab_pair(nz.z, nz.w, r.oz, r.iz, az[2], az[3]);
-    slab_pair(fz.x, fz.y, r.oz, r.iz, bz[0], bz[1]); slab_pair(fz.z, fz.w, r.oz, r.iz, bz[2], bz[3]);
-    const bool odd = fminf(fminf(r.ix, r.iy), r.iz) == -RT_INF;
-    if (__any(odd)) {
-        if (odd) {
-            auto redo = [](float& a, float& b, bool s) {       // t0,t1 as the reference has them, then its swap
-                const float t0 = s ? b : a, t1 = s ? a : b;
-                const bool sw = t1 < t0;
-                a = sw ? t1 : t0;
-                b = sw ? t0 : t1;
-            };
-#pragma unroll
-            for (int k = 0; k < 4; k++) { redo(ax[k], bx[k], sx); redo(ay[k], by[k], sy); redo(az[k], bz[k], sz); }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const float tMin = fmaxf(fmaxf(fmaxf(0.0f, ax[k]), ay[k]), az[k]);
-        const float tMax = fminf(fminf(fminf(tmax, bx[k]), by[k]), bz[k]);
-        te[k] = tMin;
-        hit[k] = (tMin <= tMax) && (tMax > 0.0f);
-    }
-}
+#include "rt_box.h"   // ActiveRay, box_test, node_slabs4
 
 // IntersectsTriangle_Bary, raytracer.cpp:896-947, with col_A0/col_A1 preloaded.
 // Straight-line form: the reference's early returns become one verdict (each
@@ -704,7 +624,8 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     const uint4 lk = *reinterpret_cast<const uint4*>(nb + 96u);
                     float te4[4];
                     bool hit4[4];
-                    node_slabs4(ar, nx, fx, ny, fy, nz, fz, sx != 0u, sy != 0u, sz != 0u, tmax, te4, hit4);
+                    if (__builtin_expect(!__any(ray_is_odd(ar)), 1)) node_slabs4(ar, nx, fx, ny, fy, nz, fz, tmax, te4, hit4);
+                    else node_slabs4_any(ar, nx, fx, ny, fy, nz, fz, sx != 0u, sy != 0u, sz != 0u, tmax, te4, hit4);
                     const float t0 = te4[0], t1 = te4[1], t2 = te4[2], t3 = te4[3];
                     // slot 0 is always valid; an empty slot carries RT_LINK_DONE
                     const bool h0 = hit4[0];

@@ -1,0 +1,85 @@
+// Host build of raytracer_amd/csrc/rt_box.h (the device's ray/box arithmetic, same text) against the oracle's
+// restatement of IntersectAABB (oracle/rt_oracle.c: intersect_aabb, raytracer.cpp:815-894) over adversarial
+// operands.  Checked per case: the verdict of box_test and of node_slabs4 (every slot, both plane orders) equals
+// the reference's hit / miss, and both give the same entry distance.  Exit code 0 = all equal.
+// Built and run by tests/test_box_logic.py with clang++ -O1 -ffp-contract=off (ext_vector_type needs clang).
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+extern "C" {
+#include "../oracle/rt_oracle.c"
+}
+
+#define RT_BOX_HOST 1
+#define RT_INF __builtin_huge_valf()
+struct V3 { float x, y, z; };
+struct float4 { float x, y, z, w; };
+#include "../raytracer_amd/csrc/rt_box.h"
+
+static uint32_t bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+int main() {
+    const float den = 1e-45f, sub = 1e-39f, tiny = 1.5e-38f, inf = RT_INF;
+    const std::vector<float> dirs = {0.0f, -0.0f, den, -den, sub, -sub, tiny, -tiny, 1.0f, -1.0f, 0.3f, -0.7f, 1e30f, -1e30f};
+    const std::vector<float> planes = {-2.0f, -1.0f, -0.0f, 0.0f, 0.5f, 1.0f, 3.0f};
+    const std::vector<float> origins = {-5.0f, -2.0f, -1.0f, -0.5f, -0.0f, 0.0f, 0.25f, 0.5f, 1.0f, 2.0f, 3.0f, 7.0f, 1e-40f, -1e-40f};
+    const std::vector<float> bounds = {3.402823466e+38F, 10.0f, 1.0f, 0.5f, 1e-3f, 0.0f, -1.0f, inf};
+    unsigned long long cases = 0, bad = 0, odd_cases = 0;
+    // one axis varies adversarially at a time, the two others take a few ordinary and a few degenerate settings
+    struct Axis { float d, o, mn, mx; };
+    std::vector<Axis> hard, easy;
+    for (float d : dirs) for (float o : origins) for (float mn : planes) for (float mx : planes) if (mn <= mx) hard.push_back({d, o, mn, mx});
+    easy = {{1.0f, -3.0f, -1.0f, 1.0f}, {-0.5f, 2.0f, -1.0f, 1.0f}, {0.0f, 0.0f, -1.0f, 1.0f}, {0.0f, 1.0f, -1.0f, 1.0f}, {-0.0f, 2.0f, -1.0f, 1.0f},
+            {-sub, -1.0f, -1.0f, 1.0f}, {-sub, 0.0f, -1.0f, 1.0f}, {sub, 1.0f, -1.0f, 1.0f}, {0.25f, 0.0f, 0.0f, 0.0f}};
+    for (int axis = 0; axis < 3; axis++)
+        for (const Axis& h : hard)
+            for (const Axis& e1 : easy)
+                for (size_t e2i = 0; e2i < easy.size(); e2i += 2) {
+                    const Axis& e2 = easy[e2i];
+                    Axis ax[3];
+                    ax[axis] = h; ax[(axis + 1) % 3] = e1; ax[(axis + 2) % 3] = e2;
+                    for (float minT : bounds) {
+                        ray_t r;
+                        std::memset(&r, 0, sizeof(r));
+                        r.o.x = ax[0].o; r.o.y = ax[1].o; r.o.z = ax[2].o;
+                        r.d.x = ax[0].d; r.d.y = ax[1].d; r.d.z = ax[2].d;
+                        const float bmin[3] = {ax[0].mn, ax[1].mn, ax[2].mn}, bmax[3] = {ax[0].mx, ax[1].mx, ax[2].mx};
+                        const bool ref_hit = intersect_aabb(&r, bmin, bmax, minT) != RAY_MISS;
+                        ActiveRay ar;
+                        ar.set(V3{r.o.x, r.o.y, r.o.z}, V3{r.d.x, r.d.y, r.d.z});
+                        if (fminf(fminf(ar.ix, ar.iy), ar.iz) == -inf) odd_cases++;
+                        float te = 0.f;
+                        const bool h1 = box_test(ar, bmin[0], bmin[1], bmin[2], bmax[0], bmax[1], bmax[2], minT, te);
+                        // the record as the device reads it: near / far planes picked by the sign of 1/d; the box sits in slot k,
+                        // the other slots hold another box
+                        const bool sx = bits(ar.ix) >> 31, sy = bits(ar.iy) >> 31, sz = bits(ar.iz) >> 31;
+                        for (int k = 0; k < 4; k++) {
+                            float mn[3][4], mx[3][4];
+                            for (int a = 0; a < 3; a++) for (int j = 0; j < 4; j++) { mn[a][j] = (j == k) ? bmin[a] : -9.0f + j; mx[a][j] = (j == k) ? bmax[a] : 9.0f + j; }
+                            auto f4 = [](const float* p) { return float4{p[0], p[1], p[2], p[3]}; };
+                            float te4[4];
+                            bool hit4[4];
+                            // as the node step calls them: the fast form unless the ray has an infinite 1/d
+                            if (!ray_is_odd(ar))
+                                node_slabs4(ar, f4(sx ? mx[0] : mn[0]), f4(sx ? mn[0] : mx[0]), f4(sy ? mx[1] : mn[1]), f4(sy ? mn[1] : mx[1]),
+                                            f4(sz ? mx[2] : mn[2]), f4(sz ? mn[2] : mx[2]), minT, te4, hit4);
+                            else
+                                node_slabs4_any(ar, f4(sx ? mx[0] : mn[0]), f4(sx ? mn[0] : mx[0]), f4(sy ? mx[1] : mn[1]), f4(sy ? mn[1] : mx[1]),
+                                                f4(sz ? mx[2] : mn[2]), f4(sz ? mn[2] : mx[2]), sx, sy, sz, minT, te4, hit4);
+                            cases++;
+                            const bool same_te = !h1 || bits(te4[k]) == bits(te) || (te4[k] == 0.0f && te == 0.0f);
+                            if (hit4[k] != ref_hit || h1 != ref_hit || !same_te) {
+                                if (bad++ < 10)
+                                    std::printf("MISMATCH o=(%g %g %g) d=(%g %g %g) box=(%g %g %g)-(%g %g %g) minT=%g: reference %d box_test %d (te %g) node_slabs4[%d] %d (te %g)\n",
+                                                r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, bmin[0], bmin[1], bmin[2], bmax[0], bmax[1], bmax[2], minT,
+                                                (int)ref_hit, (int)h1, te, k, (int)hit4[k], te4[k]);
+                            }
+                        }
+                    }
+                }
+    std::printf("%llu cases (%llu of them with 1/d = -inf on some axis), %llu mismatches\n", cases / 4, odd_cases, bad);
+    return bad ? 1 : 0;
+}
