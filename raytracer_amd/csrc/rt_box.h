@@ -1,8 +1,9 @@
-// rt_box.h — the ray/box arithmetic of the traversal (IntersectAABB, raytracer.cpp:815-894), kept free of
-// HIP-only constructs so that tests/box_logic.cpp can compile the very same text for the host and compare
-// it with the oracle's restatement of the reference over adversarial operands (zero and denormal direction
-// components, origins on box planes, degenerate boxes, infinities).  Device builds include it through
-// rt_traverse.h; the host test defines RT_BOX_HOST and supplies V3 / float4 / RT_INF itself.
+// rt_box.h — the ray/box and ray/primitive arithmetic of the traversal (IntersectAABB, IntersectsTriangle_Bary,
+// IntersectSphere, IntersectsPlane: raytracer.cpp:815-999), kept free of wave-level constructs so that
+// tests/box_logic.cpp can compile the very same text for the host and compare it with the oracle's restatement
+// of the reference over adversarial operands (zero and denormal direction components, origins on box planes,
+// degenerate boxes and triangles, infinities).  Device builds include it through rt_traverse.h, after
+// rt_device.h; the host test defines RT_BOX_HOST and includes rt_device.h over tests/shim/hip/hip_runtime.h.
 #pragma once
 #ifdef RT_BOX_HOST
 #define RT_BOX_FN static inline
@@ -130,5 +131,60 @@ RT_BOX_FN void node_slabs4_any(const ActiveRay& r, float4 nx, float4 fx, float4 
     } else {
         node_slabs4(r, nx, fx, ny, fy, nz, fz, tmax, te, hit);
     }
+}
+
+// IntersectsTriangle_Bary, raytracer.cpp:896-947, with col_A0/col_A1 preloaded.
+// Straight-line form: the reference's early returns become one verdict (each
+// condition is evaluated on the same values in the same order; a quotient by a
+// detA that failed the first test is computed but never looked at), so a wave
+// whose lanes test different triangles executes no divergent branches.
+RT_BOX_FN bool tri_test(const ActiveRay& r, float ax, float ay, float az, float e1x, float e1y,
+                                         float e1z, float e2x, float e2y, float e2z, float minT, float& t_out,
+                                         float& beta_out, float& gamma_out) {
+    const float bx = ax - r.ox, by = ay - r.oy, bz = az - r.oz;
+    const float detA = det3x3(e1x, e2x, r.dx, e1y, e2y, r.dy, e1z, e2z, r.dz);
+    const float beta = det3x3(bx, e2x, r.dx, by, e2y, r.dy, bz, e2z, r.dz) / detA;
+    const float gamma = det3x3(e1x, bx, r.dx, e1y, by, r.dy, e1z, bz, r.dz) / detA;
+    const float t = det3x3(e1x, e2x, bx, e1y, e2y, by, e1z, e2z, bz) / detA;
+    const bool rej = (fabsf(detA) < RT_EPS_PARALLEL) | (beta < -RT_EPS_PARALLEL) | (gamma < -RT_EPS_PARALLEL) |
+                     ((beta + gamma) > (1.0f + RT_EPS_PARALLEL)) | (t < -RT_EPS_PARALLEL) | (t >= minT);
+    t_out = t;
+    beta_out = beta;
+    gamma_out = gamma;
+    return !rej;
+}
+
+// IntersectSphere, raytracer.cpp:949-980 (sqrt(double(delta)) narrowed to float
+// is the correctly rounded sqrtf: 53 >= 2*24+2).
+RT_BOX_FN bool sphere_test(const ActiveRay& r, float cx, float cy, float cz, float radius, float minT,
+                                            float& t_out) {
+    V3 oc = mk(r.ox - cx, r.oy - cy, r.oz - cz);
+    V3 d = mk(r.dx, r.dy, r.dz);
+    float A = dot(d, d);
+    float B = 2 * dot(d, oc);
+    float C = dot(oc, oc) - radius * radius;
+    float delta = B * B - 4 * A * C;
+    if (delta < 0.0f) return false;
+    float sq = sqrtf(delta);
+    float t1 = (-B - sq) / (2 * A);
+    float t2 = (-B + sq) / (2 * A);
+    float t;
+    if (t1 > 0.0f) t = t1;
+    else if (t2 > 0.0f) t = t2;
+    else return false;
+    if (t >= minT) return false;
+    t_out = t;
+    return true;
+}
+
+// IntersectsPlane, raytracer.cpp:982-999
+RT_BOX_FN bool plane_test(V3 o, V3 d, const DPlane& p, float minT, float& t_out) {
+    V3 n = mk(p.nx, p.ny, p.nz);
+    float den = dot(d, n);
+    if (fabsf(den) < RT_EPS_PARALLEL) return false;
+    float t = -(dot(o, n) + p.d) / den;
+    if (t < 0.0f || t >= minT) return false;
+    t_out = t;
+    return true;
 }
 

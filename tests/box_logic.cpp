@@ -1,7 +1,9 @@
-// Host build of raytracer_amd/csrc/rt_box.h (the device's ray/box arithmetic, same text) against the oracle's
-// restatement of IntersectAABB (oracle/rt_oracle.c: intersect_aabb, raytracer.cpp:815-894) over adversarial
-// operands.  Checked per case: the verdict of box_test and of node_slabs4 (every slot, both plane orders) equals
-// the reference's hit / miss, and both give the same entry distance.  Exit code 0 = all equal.
+// Host build of raytracer_amd/csrc/rt_box.h (the device's ray/box and ray/primitive arithmetic, same text) against
+// the oracle's restatements (oracle/rt_oracle.c: intersect_aabb, intersects_triangle, intersect_sphere,
+// intersect_plane; raytracer.cpp:815-999) over adversarial operands.  Boxes: the verdict of box_test and of
+// node_slabs4 (every slot, both plane orders) equals the reference's hit / miss, and both give the same entry
+// distance.  Triangles, spheres, planes: same verdict, and on a hit the same bits of t (and beta, gamma).
+// Exit code 0 = all equal.
 // Built and run by tests/test_box_logic.py with clang++ -O1 -ffp-contract=off (ext_vector_type needs clang).
 #include <cmath>
 #include <cstdint>
@@ -9,15 +11,25 @@
 #include <cstring>
 #include <vector>
 
+#include <float.h>
+#include <math.h>
+#include <omp.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define RT_BOX_HOST 1
+#include "../raytracer_amd/csrc/rt_device.h"     // over tests/shim/hip/hip_runtime.h (-I tests/shim)
+#include "../raytracer_amd/csrc/rt_box.h"
+
+namespace orc {          // the oracle's statics (q_rsqrt, det3x3, ...) share names with the device's
 extern "C" {
 #include "../oracle/rt_oracle.c"
 }
-
-#define RT_BOX_HOST 1
-#define RT_INF __builtin_huge_valf()
-struct V3 { float x, y, z; };
-struct float4 { float x, y, z, w; };
-#include "../raytracer_amd/csrc/rt_box.h"
+}
+using orc::ray_t;
+using orc::v3;
 
 static uint32_t bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
@@ -47,7 +59,7 @@ int main() {
                         r.o.x = ax[0].o; r.o.y = ax[1].o; r.o.z = ax[2].o;
                         r.d.x = ax[0].d; r.d.y = ax[1].d; r.d.z = ax[2].d;
                         const float bmin[3] = {ax[0].mn, ax[1].mn, ax[2].mn}, bmax[3] = {ax[0].mx, ax[1].mx, ax[2].mx};
-                        const bool ref_hit = intersect_aabb(&r, bmin, bmax, minT) != RAY_MISS;
+                        const bool ref_hit = orc::intersect_aabb(&r, bmin, bmax, minT) != RAY_MISS;
                         ActiveRay ar;
                         ar.set(V3{r.o.x, r.o.y, r.o.z}, V3{r.d.x, r.d.y, r.d.z});
                         if (fminf(fminf(ar.ix, ar.iy), ar.iz) == -inf) odd_cases++;
@@ -80,6 +92,73 @@ int main() {
                         }
                     }
                 }
-    std::printf("%llu cases (%llu of them with 1/d = -inf on some axis), %llu mismatches\n", cases / 4, odd_cases, bad);
+    std::printf("boxes: %llu cases (%llu of them with 1/d = -inf on some axis), %llu mismatches\n", cases / 4, odd_cases, bad);
+
+    // ---- triangles, spheres, planes: seeded random operands mixed with degenerate ones
+    unsigned long long pcases = 0, pbad = 0, phits = 0;
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)(st >> 32); };
+    auto uni = [&](float lo, float hi) { return lo + (hi - lo) * (float)(rnd() >> 8) * (1.0f / 16777216.0f); };
+    const float special[] = {0.0f, -0.0f, 1.0f, -1.0f, 1e-20f, -1e-20f, 1e-39f, 1e20f, 0.5f, 2.0f, 1e-8f, -1e-8f};
+    auto val = [&](float lo, float hi) { return (rnd() % 5 == 0) ? special[rnd() % 12] : uni(lo, hi); };
+    for (int it = 0; it < 3000000; it++) {
+        ray_t r;
+        std::memset(&r, 0, sizeof(r));
+        r.o.x = val(-3, 3); r.o.y = val(-3, 3); r.o.z = val(-3, 3);
+        r.d.x = val(-1, 1); r.d.y = val(-1, 1); r.d.z = val(-1, 1);
+        const float minT = (rnd() % 4 == 0) ? bounds[rnd() % bounds.size()] : uni(0.0f, 8.0f);
+        ActiveRay ar;
+        ar.set(V3{r.o.x, r.o.y, r.o.z}, V3{r.d.x, r.d.y, r.d.z});
+        {   // triangle: three vertices, sometimes coincident / collinear / through the origin of the ray
+            rt_vertex vd[3];
+            std::memset(vd, 0, sizeof(vd));
+            for (int v = 0; v < 3; v++) for (int c = 0; c < 3; c++) vd[v].pos[c] = val(-3, 3);
+            if (rnd() % 16 == 0) std::memcpy(vd[1].pos, vd[0].pos, 12);
+            if (rnd() % 16 == 0) { vd[2].pos[0] = r.o.x; vd[2].pos[1] = r.o.y; vd[2].pos[2] = r.o.z; }
+            rt_face f;
+            std::memset(&f, 0, sizeof(f));
+            f.i0 = 1; f.i1 = 2; f.i2 = 3;
+            float rb = 0.f, rg = 0.f;
+            const float rt_ = orc::intersect_triangle(&r, &f, vd, minT, &rb, &rg);
+            const float* a = vd[0].pos; const float* b = vd[1].pos; const float* c = vd[2].pos;
+            float t = 0.f, bb = 0.f, gg = 0.f;
+            const bool h = tri_test(ar, a[0], a[1], a[2], a[0] - b[0], a[1] - b[1], a[2] - b[2], a[0] - c[0], a[1] - c[1], a[2] - c[2], minT, t, bb, gg);
+            pcases++;
+            const bool ref_hit = rt_ != RAY_MISS;
+            phits += ref_hit;
+            if (h != ref_hit || (h && (bits(t) != bits(rt_) || bits(bb) != bits(rb) || bits(gg) != bits(rg)))) {
+                if (pbad++ < 10) std::printf("TRIANGLE MISMATCH reference %d (t %g) device %d (t %g) minT %g\n", (int)ref_hit, rt_, (int)h, t, minT);
+            }
+        }
+        {   // sphere
+            const v3 cen = {val(-3, 3), val(-3, 3), val(-3, 3)};
+            const float rad = (rnd() % 8 == 0) ? special[rnd() % 12] : uni(0.01f, 2.0f);
+            const float rt_ = orc::intersect_sphere(&r, cen, rad, minT);
+            float t = 0.f;
+            const bool h = sphere_test(ar, cen.x, cen.y, cen.z, rad, minT, t);
+            pcases++;
+            phits += rt_ != RAY_MISS;
+            if (h != (rt_ != RAY_MISS) || (h && bits(t) != bits(rt_))) {
+                if (pbad++ < 10) std::printf("SPHERE MISMATCH reference t %g device %d (t %g)\n", rt_, (int)h, t);
+            }
+        }
+        {   // plane
+            DPlane p;
+            std::memset(&p, 0, sizeof(p));
+            p.nx = val(-1, 1); p.ny = val(-1, 1); p.nz = val(-1, 1); p.d = val(-3, 3);
+            const v3 n = {p.nx, p.ny, p.nz};
+            const float rt_ = orc::intersect_plane(&r, n, p.d, minT);
+            float t = 0.f;
+            const bool h = plane_test(V3{r.o.x, r.o.y, r.o.z}, V3{r.d.x, r.d.y, r.d.z}, p, minT, t);
+            pcases++;
+            phits += rt_ != RAY_MISS;
+            if (h != (rt_ != RAY_MISS) || (h && bits(t) != bits(rt_))) {
+                if (pbad++ < 10) std::printf("PLANE MISMATCH reference t %g device %d (t %g)\n", rt_, (int)h, t);
+            }
+        }
+    }
+    std::printf("triangles / spheres / planes: %llu cases (%llu hits), %llu mismatches\n", pcases, phits, pbad);
+    bad += pbad;
+    std::printf("total: %llu mismatches\n", bad);
     return bad ? 1 : 0;
 }
