@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "rt.h"
@@ -265,6 +266,7 @@ BvhLayout layout_bvh(const rt_bvh_node* nodes, uint32_t count, uint32_t leaf_bas
                      std::vector<DBigLeaf>& big, uint32_t base = 0) {
     BvhLayout L;
     if (count == 0) return L;
+    out.reserve(out.size() + count / 2 + 16);       // one record per interior node of every other level
     BvhBuilder4 b{nodes, leaf_base, top, out, big, base};
     L.root_link = nodes[0].prim_count > 0 ? b.leaf_link(nodes[0]) : b.build(0);
     std::memcpy(L.rmin, nodes[0].bmin, 12);
@@ -308,12 +310,20 @@ void fill_object_common(DObject& o, uint32_t flags, const float* M, const float*
 uint64_t hash_bytes(uint64_t h, const void* p, size_t n) {
     const uint8_t* b = (const uint8_t*)p;
     size_t i = 0;
-    for (; i + 8 <= n; i += 8) {
-        uint64_t w;
-        std::memcpy(&w, b + i, 8);
-        h = (h ^ w) * 0x9E3779B97F4A7C15ull;
-        h ^= h >> 29;
+    // four independent multiply-xor chains over 32-byte blocks (one chain is latency-bound), folded at the end
+    uint64_t h0 = h, h1 = h ^ 0x243F6A8885A308D3ull, h2 = h ^ 0x13198A2E03707344ull, h3 = h ^ 0xA4093822299F31D0ull;
+    for (; i + 32 <= n; i += 32) {
+        uint64_t w[4];
+        std::memcpy(w, b + i, 32);
+        h0 = (h0 ^ w[0]) * 0x9E3779B97F4A7C15ull; h0 ^= h0 >> 29;
+        h1 = (h1 ^ w[1]) * 0x9E3779B97F4A7C15ull; h1 ^= h1 >> 29;
+        h2 = (h2 ^ w[2]) * 0x9E3779B97F4A7C15ull; h2 ^= h2 >> 29;
+        h3 = (h3 ^ w[3]) * 0x9E3779B97F4A7C15ull; h3 ^= h3 >> 29;
     }
+    h = h0;
+    h = (h ^ h1) * 0x9E3779B97F4A7C15ull; h ^= h >> 29;
+    h = (h ^ h2) * 0x9E3779B97F4A7C15ull; h ^= h >> 29;
+    h = (h ^ h3) * 0x9E3779B97F4A7C15ull; h ^= h >> 29;
     for (; i < n; i++) h = (h ^ b[i]) * 0x100000001B3ull;
     return h;
 }
@@ -327,49 +337,101 @@ uint64_t mesh_hash(const rt_scene_desc* s) {
     return h;
 }
 
+// Upload-time re-layout on the device: the leaf-ordered triangle records and their shading twins are gathered
+// from the reference's own arrays (primIdx -> prims[].faceIdx -> faces[] -> vertex_data[], raytracer.cpp:783-789),
+// with the same FP32 subtractions the host would do (col_A0 = a - b, col_A1 = a - c, raytracer.cpp:902-903).
+__global__ void __launch_bounds__(256) k_build_tris(const uint32_t* __restrict__ prim_face, const rt_face* __restrict__ faces,
+                                                    const rt_vertex* __restrict__ vd, uint32_t prim_offset, uint32_t face_offset,
+                                                    uint32_t n, DTri* __restrict__ tris, DTriShade* __restrict__ tshade) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t fi = prim_face[prim_offset + p];
+    const rt_face f = faces[face_offset + fi];
+    const float* a = vd[f.i0 - 1].pos;
+    const float* b = vd[f.i1 - 1].pos;
+    const float* c = vd[f.i2 - 1].pos;
+    const float ax = a[0], ay = a[1], az = a[2];
+    DTri t;
+    t.ax = ax; t.ay = ay; t.az = az;
+    t.e1x = ax - b[0]; t.e1y = ay - b[1]; t.e1z = az - b[2];
+    t.e2x = ax - c[0]; t.e2y = ay - c[1]; t.e2z = az - c[2];
+    tris[prim_offset + p] = t;
+    DTriShade ts;
+    ts.nx = f.n_unit[0]; ts.ny = f.n_unit[1]; ts.nz = f.n_unit[2];
+    ts.i0 = f.i0; ts.i1 = f.i1; ts.i2 = f.i2;
+    ts.face = fi;
+    ts.pad = 0;
+    tshade[prim_offset + p] = ts;
+}
+__global__ void __launch_bounds__(256) k_build_vnormals(const rt_vertex* __restrict__ vd, uint32_t n, float4* __restrict__ vn) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) vn[i] = make_float4(vd[i].normal[0], vd[i].normal[1], vd[i].normal[2], 0.f);
+}
+
+// RT_UPLOAD_TIMING=1: phase times of rt_upload_scene on stderr
+struct PhaseClock {
+    bool on = getenv("RT_UPLOAD_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rt upload] %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
 // The mesh level: collapsed mesh BVHs, leaf-ordered triangle records, shading data, vertex normals.
 int build_mesh_level(rt_scene* sc, const rt_scene_desc* s) {
+    PhaseClock pc;
     std::vector<DNode4> nodes;
     std::vector<DBigLeaf> big;
-    std::vector<DTri> tris(s->n_mesh_prims);
-    std::vector<DTriShade> tshade(s->n_mesh_prims);
 
-    // mesh BVHs
+    // mesh BVHs: the node records are collapsed on the host (a sequential walk, a few ms per million triangles)
     std::vector<BvhLayout> mesh_layout(s->n_mesh_bvhs);
     bool donate_ok = true;
     for (uint32_t b = 0; b < s->n_mesh_bvhs; b++) {
         const rt_mesh_bvh& mb = s->mesh_bvhs[b];
         mesh_layout[b] = layout_bvh(s->mesh_nodes + mb.node_offset, mb.node_count, mb.prim_offset, false, nodes, big);
-        if (!leaves_ascending(s->mesh_nodes + mb.node_offset, mb.node_count)) donate_ok = false;
-        for (uint32_t p = 0; p < mb.prim_count; p++) {
-            const uint32_t fi = s->mesh_prim_face[mb.prim_offset + p];
-            const rt_face& f = s->faces[mb.face_offset + fi];
-            const float* a = s->vertex_data[f.i0 - 1].pos;
-            const float* bb = s->vertex_data[f.i1 - 1].pos;
-            const float* c = s->vertex_data[f.i2 - 1].pos;
-            DTri& t = tris[mb.prim_offset + p];
-            t.ax = a[0]; t.ay = a[1]; t.az = a[2];
-            t.e1x = a[0] - bb[0]; t.e1y = a[1] - bb[1]; t.e1z = a[2] - bb[2];   // col_A0, raytracer.cpp:902
-            t.e2x = a[0] - c[0];  t.e2y = a[1] - c[1];  t.e2z = a[2] - c[2];    // col_A1, raytracer.cpp:903
-            DTriShade& ts = tshade[mb.prim_offset + p];
-            ts.face = fi;
-            ts.pad = 0;
-            ts.nx = f.n_unit[0]; ts.ny = f.n_unit[1]; ts.nz = f.n_unit[2];
-            ts.i0 = f.i0; ts.i1 = f.i1; ts.i2 = f.i2;
-        }
     }
-
-    std::vector<float4> vn(s->n_vertices);
-    for (uint32_t i = 0; i < s->n_vertices; i++)
-        vn[i] = make_float4(s->vertex_data[i].normal[0], s->vertex_data[i].normal[1], s->vertex_data[i].normal[2], 0.f);
-    if (nodes.size() >= 0x7FFFFFF0u - 2ull * s->n_top_nodes || tris.size() >= RT_LEAF_MAX_FIRST)
+    pc.lap("mesh BVH layout (host)");
+    for (uint32_t b = 0; b < s->n_mesh_bvhs; b++)
+        if (!leaves_ascending(s->mesh_nodes + s->mesh_bvhs[b].node_offset, s->mesh_bvhs[b].node_count)) donate_ok = false;
+    pc.lap("leaf order check (host)");
+    if (nodes.size() >= 0x7FFFFFF0u - 2ull * s->n_top_nodes || s->n_mesh_prims >= RT_LEAF_MAX_FIRST)
         return fail(RT_ERR_UNSUPPORTED, "scene too large for the link encoding (2^26 leaf prims)");
 
     int rc;
     // the top level's records follow the meshes' in the same array: leave room for them (rt_update_scene grows it if needed)
     if ((rc = sc->b_nodes.ensure((nodes.size() + std::max<size_t>(1024, 2 * (size_t)s->n_top_nodes)) * sizeof(DNode4)))) return rc;
     if (!nodes.empty()) HIPCHK(hipMemcpy(sc->b_nodes.p, nodes.data(), nodes.size() * sizeof(DNode4), hipMemcpyHostToDevice));
-    if ((rc = upload_vec(sc->b_tris, tris)) || (rc = upload_vec(sc->b_tri_shade, tshade)) || (rc = upload_vec(sc->b_vnormals, vn))) return rc;
+    // triangle records, shading records and vertex normals: gathered on the device from the caller's arrays
+    if ((rc = sc->b_tris.ensure(std::max<size_t>(s->n_mesh_prims, 1) * sizeof(DTri))) ||
+        (rc = sc->b_tri_shade.ensure(std::max<size_t>(s->n_mesh_prims, 1) * sizeof(DTriShade))) ||
+        (rc = sc->b_vnormals.ensure(std::max<size_t>(s->n_vertices, 1) * sizeof(float4))))
+        return rc;
+    {
+        DevBuf d_prim_face, d_faces, d_vd;
+        struct Release { DevBuf &a, &b, &c; ~Release() { a.release(); b.release(); c.release(); } } rel{d_prim_face, d_faces, d_vd};
+        if ((rc = d_prim_face.ensure(std::max<size_t>(s->n_mesh_prims, 1) * sizeof(uint32_t))) ||
+            (rc = d_faces.ensure(std::max<size_t>(s->n_faces, 1) * sizeof(rt_face))) ||
+            (rc = d_vd.ensure(std::max<size_t>(s->n_vertices, 1) * sizeof(rt_vertex))))
+            return rc;
+        if (s->n_mesh_prims) HIPCHK(hipMemcpy(d_prim_face.p, s->mesh_prim_face, (size_t)s->n_mesh_prims * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (s->n_faces) HIPCHK(hipMemcpy(d_faces.p, s->faces, (size_t)s->n_faces * sizeof(rt_face), hipMemcpyHostToDevice));
+        if (s->n_vertices) HIPCHK(hipMemcpy(d_vd.p, s->vertex_data, (size_t)s->n_vertices * sizeof(rt_vertex), hipMemcpyHostToDevice));
+        for (uint32_t b = 0; b < s->n_mesh_bvhs; b++) {
+            const rt_mesh_bvh& mb = s->mesh_bvhs[b];
+            if (mb.prim_count == 0) continue;
+            k_build_tris<<<(mb.prim_count + 255) / 256, 256, 0, sc->stream>>>((const uint32_t*)d_prim_face.p, (const rt_face*)d_faces.p, (const rt_vertex*)d_vd.p,
+                                                                           mb.prim_offset, mb.face_offset, mb.prim_count, (DTri*)sc->b_tris.p,
+                                                                           (DTriShade*)sc->b_tri_shade.p);
+        }
+        if (s->n_vertices)
+            k_build_vnormals<<<(s->n_vertices + 255) / 256, 256, 0, sc->stream>>>((const rt_vertex*)d_vd.p, s->n_vertices, (float4*)sc->b_vnormals.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(sc->stream));
+    }
+    pc.lap("copies + device re-layout");
 
     rt_scene::MeshLevel& M = sc->mesh;
     M.roots.resize(s->n_mesh_bvhs);
@@ -383,6 +445,7 @@ int build_mesh_level(rt_scene* sc, const rt_scene_desc* s) {
     M.n_mesh_bvhs = s->n_mesh_bvhs; M.n_mesh_nodes = s->n_mesh_nodes; M.n_mesh_prims = s->n_mesh_prims;
     M.n_faces = s->n_faces; M.n_vertices = s->n_vertices;
     M.hash = mesh_hash(s);
+    pc.lap("mesh hash");
     M.donate_ok = donate_ok;
     sc->ds.tris = (const DTri*)sc->b_tris.p;
     sc->ds.tri_shade = (const DTriShade*)sc->b_tri_shade.p;
@@ -837,8 +900,10 @@ int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out) {
     int n = rt_device_count();
     if (n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= n) return fail(RT_ERR_NO_DEVICE, "device %d out of range [0,%d)", device, n);
+    PhaseClock pc;
     int rc = validate_scene(scene);
     if (rc) return rc;
+    pc.lap("validate_scene");
     HIPCHK(hipSetDevice(device));
     rt_scene* sc = new rt_scene();
     sc->device = device;
