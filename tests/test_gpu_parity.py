@@ -238,3 +238,47 @@ def test_update_scene_keeps_meshes_and_equals_oracle(rt):
     rgb, _ = ds.render(hs.camera(0))
     assert (rgb == ob.render(hs, hs.camera(0))[0]).all()
     ds.close()
+
+
+@pytest.mark.gpu
+def test_degenerate_scenes_vs_oracle(rt):
+    """Nothing to hit; planes only; no lights; a mesh that is a single triangle (its BVH root is a leaf, no node
+    records at all); a scaled instance of it looked at along an axis (rays with zero direction components and an
+    infinite object-space bound, the case rt_box.h treats literally)."""
+    from raytracer_amd import scenes
+    cam = dict(position=(0.0, 0.0, 5.0), gaze_point=(0, 0, 0), up=(0, 1, 0), fovy=40.0, near=1.0, width=65, height=33, num_samples=1)
+    mat = dict(ambient=(1, 1, 1), diffuse=(0.7, 0.6, 0.5), specular=(0.4, 0.4, 0.4), phong=20.0)
+    mirror = dict(type=rt.ffi.RT_MAT_MIRROR, ambient=(0.1, 0.1, 0.1), diffuse=(0.2, 0.2, 0.2), specular=(1, 1, 1), mirror=(0.8, 0.8, 0.8), phong=50.0)
+
+    def base(name):
+        s = scenes.SynthScene(name)
+        s.background = (30, 60, 90)
+        s.max_depth = 3
+        s.vertices = [(0, -1, 0), (-1, -1, -1), (1, -1, -1), (0, 1, -1)]
+        s.materials = [dict(mat), dict(mirror)]
+        s.camera = dict(cam)
+        return s
+
+    cases = []
+    s = base("nothing")
+    cases.append(s)
+    s = base("planes_no_lights")
+    s.planes = [dict(point=1, normal=(0, 1, 0), material=1)]
+    cases.append(s)
+    s = base("plane_and_light")
+    s.planes = [dict(point=1, normal=(0, 1, 0), material=2)]
+    s.point_lights = [((2, 4, 3), (30000, 30000, 30000))]
+    cases.append(s)
+    s = base("one_triangle")
+    s.point_lights = [((2, 4, 3), (30000, 30000, 30000))]
+    s.meshes = [dict(verts=None, faces=np.array([[2, 3, 4]], np.int32), material=1)]
+    cases.append(s)
+    s = base("scaled_instance_axis_aligned_view")
+    s.point_lights = [((0, 0, 6), (30000, 30000, 30000))]
+    s.planes = [dict(point=1, normal=(0, 1, 0), material=2)]
+    s.meshes = [dict(verts=None, faces=np.array([[2, 3, 4]], np.int32), material=1)]
+    s.instances = [dict(base=0, material=1, transform=[("s", (0.25, 0.25, 0.25)), ("t", (0.0, 0.0, 1.0))], reset=False)]
+    s.camera = dict(cam, width=33, height=33)      # odd size: the centre pixel looks straight down -z unless jittered
+    cases.append(s)
+    for spec in cases:
+        _vs_oracle(rt, spec)
