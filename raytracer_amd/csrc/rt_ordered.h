@@ -110,6 +110,23 @@ struct LaneShadowIO {
     __device__ __forceinline__ void store(uint32_t, bool shadow, const HitOut&, float) const { L.has = shadow; L.req = OREQ_NONE; }
 };
 
+// Both kinds in one trace loop (trace_persistent MODE 2): the lane's request says which its ray is.
+struct LaneMixedIO {
+    const DScene& S;
+    LaneTrace& L;
+    uint32_t lane;
+    __device__ __forceinline__ int load(uint32_t i, V3& o, V3& d, float& time, float& minT, bool& has, HitOut& h, bool& any) const {
+        if (i != lane) { L.bad_item = 1; return 0; }
+        if (L.req == OREQ_CLOSEST) { any = false; return LaneClosestIO{S, L, lane}.load(i, o, d, time, minT, has, h); }
+        if (L.req == OREQ_ANYHIT) { any = true; return LaneShadowIO{S, L, lane}.load(i, o, d, time, minT, has, h); }
+        return 0;
+    }
+    __device__ __forceinline__ void store(uint32_t i, bool verdict, const HitOut& h, float minT) const {
+        if (L.req == OREQ_ANYHIT) LaneShadowIO{S, L, lane}.store(i, verdict, h, minT);
+        else LaneClosestIO{S, L, lane}.store(i, verdict, h, minT);
+    }
+};
+
 struct OrderedArgs {
     DCamera cam;
     ChunkGeom g;
@@ -430,18 +447,29 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
             if (!__any(!done)) break;
 
             // ---- the wave traces what its lanes asked for
+#ifdef RT_ORDERED_TWO_LOOPS
             if (__any(L.req == OREQ_CLOSEST)) {
                 if (ww.lane == 0) s_cursor[ww.wave] = 0;
                 LaneClosestIO io{S, L, ww.lane};
                 unsigned long long traced = 0;
-                trace_persistent<false, false>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
+                trace_persistent<0, false>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
             }
             if (__any(L.req == OREQ_ANYHIT)) {
                 if (ww.lane == 0) s_cursor[ww.wave] = 0;
                 LaneShadowIO io{S, L, ww.lane};
                 unsigned long long traced = 0;
-                trace_persistent<true, false>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
+                trace_persistent<1, false>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
             }
+#else
+            // closest-hit and any-hit requests share one loop: all lanes with a request are busy in it together,
+            // and the kernel holds one copy of the traversal instead of two
+            if (__any(L.req != OREQ_NONE)) {
+                if (ww.lane == 0) s_cursor[ww.wave] = 0;
+                LaneMixedIO io{S, L, ww.lane};
+                unsigned long long traced = 0;
+                trace_persistent<2, false>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
+            }
+#endif
         }
     }
 #undef OFR

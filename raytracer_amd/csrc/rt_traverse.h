@@ -322,13 +322,19 @@ __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int src) { return (ui
 //   result itself and returns 1 (a ray that needs no traversal) or 0 (no ray);
 //   IO::store(item, verdict, out, minT) stores the result of a traversed ray
 //   (verdict = has / in-shadow).
-template <bool ANYHIT, bool LINGER, class IO>
+template <int MODE, bool LINGER, class IO>
 __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32_t end, uint32_t* cursor, TraceStack& st,
                                  unsigned long long& traced) {
-    constexpr uint32_t QCAP = ANYHIT ? RT_LEAF_QUEUE_ANY : RT_LEAF_QUEUE;
-    constexpr uint32_t STRIP = ANYHIT ? RT_STRIP_ANY : RT_STRIP;
-    constexpr uint32_t REFILL_MIN = ANYHIT ? RT_REFILL_MIN_ANY : RT_REFILL_MIN;
-    constexpr uint32_t EXIT_FEW = ANYHIT ? RT_EXIT_FEW_ANY : RT_EXIT_FEW, EXIT_WAIT = ANYHIT ? RT_EXIT_WAIT_ANY : RT_EXIT_WAIT;
+    // MODE 0: closest hit, 1: any-hit, 2: mixed — every lane's item says which it is (rt_ordered.h, where the
+    // lanes of a wave ask for both kinds at once); `lane_any` is then a per-lane value, otherwise a constant
+    constexpr bool MIXED = MODE == 2;
+    constexpr bool ANY_ONLY = MODE == 1;
+    bool lane_any = ANY_ONLY;
+#define RT_ISANY (MIXED ? lane_any : ANY_ONLY)
+    constexpr uint32_t QCAP = ANY_ONLY ? RT_LEAF_QUEUE_ANY : RT_LEAF_QUEUE;
+    constexpr uint32_t STRIP = ANY_ONLY ? RT_STRIP_ANY : RT_STRIP;
+    constexpr uint32_t REFILL_MIN = ANY_ONLY ? RT_REFILL_MIN_ANY : RT_REFILL_MIN;
+    constexpr uint32_t EXIT_FEW = ANY_ONLY ? RT_EXIT_FEW_ANY : RT_EXIT_FEW, EXIT_WAIT = ANY_ONLY ? RT_EXIT_WAIT_ANY : RT_EXIT_WAIT;
     static_assert(64 % STRIP == 0, "strips tile a 64-item block");
     static_assert(RT_LEAF_QUEUE_ANY <= RT_LEAF_QUEUE, "the LDS queue is sized by RT_LEAF_QUEUE");
     const uint32_t lane = st.lane;
@@ -411,7 +417,8 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 for (uint32_t k = 0; k < 4u && !alive; k++) {
                     uint32_t* rec = st.board + ((start + k) % st.n_board) * 16u;
                     // (rec[15]: closest-hit or any-hit subtree — in rt_ordered.h the waves of a workgroup run both kinds of loop)
-                    if (rec[0] == 2u && rec[15] == (ANYHIT ? 1u : 0u) && atomicCAS(&rec[0], 2u, 3u) == 2u) {
+                    if (rec[0] == 2u && (MIXED || rec[15] == (ANY_ONLY ? 1u : 0u)) && atomicCAS(&rec[0], 2u, 3u) == 2u) {
+                        if (MIXED) lane_any = rec[15] != 0u;
                         home = rec[1];
                         cur = rec[2];
                         cur_t = __uint_as_float(rec[3]);
@@ -471,7 +478,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                         rec[8] = __float_as_uint(ar.dx); rec[9] = __float_as_uint(ar.dy); rec[10] = __float_as_uint(ar.dz);
                         rec[11] = __float_as_uint(ar.ix); rec[12] = __float_as_uint(ar.iy); rec[13] = __float_as_uint(ar.iz);
                         rec[14] = cur_obj;
-                        rec[15] = ANYHIT ? 1u : 0u;
+                        rec[15] = RT_ISANY ? 1u : 0u;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         rec[0] = 2u;                         // ready
                         atomicAdd(&st.blk[1], 1u);
@@ -492,7 +499,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             }
             // (d) any-hit found by somebody working on the same ray: helpers drop their subtree, the owner stops
             //     its own part (pops down to the sentinel) and finishes once its helpers are gone
-            if (ANYHIT && alive && (helper || donated) && st.cancel[home] != 0) {
+            if (RT_ISANY && alive && (helper || donated) && st.cancel[home] != 0) {
                 if (helper) {
                     atomicSub(&st.out_cnt[home], 1u);
                     alive = false; helper = false; in_mesh = false; cur = RT_LINK_DONE; st.sp = 0; qn = 0;
@@ -620,7 +627,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 mesh_beta = bb;
                 mesh_gamma = gg;
             }
-            if (ANYHIT) {
+            if (RT_ISANY) {
                 // Untransformed mesh: worldT == t < testMinT == minT, so the
                 // reference's verdict is already known.
                 if (!(S.objects[cur_obj].flags & RT_OBJ_HAS_TRANSFORM)) {
@@ -741,7 +748,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         // An owner that found its any-hit while helpers still trace parts of the same ray has told them
         // (st.cancel); it drops the rest of its own part and waits at the sentinel until they are gone, so
         // that no helper of this ray is left when the slot takes its next ray.
-        if (ANYHIT && fin && !helper && donated) {
+        if (RT_ISANY && fin && !helper && donated) {
             fin = false;
             if (cur != RT_LINK_SENTINEL) cur = st.pop(-1.0f, cur_t);   // (the sentinel may already have been popped)
         }
@@ -767,7 +774,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                         if (++wait_rounds > RT_WAIT_ROUNDS_MAX) { st.overflow |= 16u; } else break;
                     }
                     wait_rounds = 0;
-                    if (ANYHIT && st.cancel[st.slot] != 0) {   // somebody found the any-hit (untransformed mesh)
+                    if (RT_ISANY && st.cancel[st.slot] != 0) {   // somebody found the any-hit (untransformed mesh)
                         donated = false;
                         fin = true;
                         finished = true;
@@ -819,7 +826,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                         const DObject& ob = S.objects[cur_obj];
                         float wt = world_t(ob, ro, time, mk(ar.ox, ar.oy, ar.oz), mk(ar.dx, ar.dy, ar.dz), tmax);
                         if (wt < minT) {
-                            if (ANYHIT) { fin = true; finished = true; break; }
+                            if (RT_ISANY) { fin = true; finished = true; break; }
                             minT = wt;
                             has = true;
                             out.kind_index = cur_kind_index;
@@ -874,7 +881,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     if (sphere_test(sr, ob.p[0], ob.p[1], ob.p[2], ob.p[3], testMinT, t)) {
                         float wt = world_t(ob, ro, time, to, td, t);
                         if (wt < minT) {
-                            if (ANYHIT) { fin = true; break; }
+                            if (RT_ISANY) { fin = true; break; }
                             minT = wt;
                             has = true;
                             out.kind_index = (RT_KIND_SPHERE << 28) | tp.index;
@@ -890,7 +897,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                                  testMinT, t, bb, gg)) {
                         float wt = world_t(ob, ro, time, to, td, t);
                         if (wt < minT) {
-                            if (ANYHIT) { fin = true; break; }
+                            if (RT_ISANY) { fin = true; break; }
                             minT = wt;
                             has = true;
                             out.kind_index = (RT_KIND_TRIANGLE << 28) | tp.index;
@@ -911,8 +918,8 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 atomicSub(&st.out_cnt[home], 1u);
             } else {
-                RT_RAYHIST({ if (ANYHIT == RT_HIST_ANY) { atomicAdd(&g_rayhist[0][32 - __clz(st.acc->ray_leaves)], 1ull); atomicAdd(&g_rayhist[1][32 - __clz(st.acc->ray_nodes)], 1ull); } })
-                io.store(item, ANYHIT ? fin : has, out, minT);
+                RT_RAYHIST({ if (ANY_ONLY == RT_HIST_ANY) { atomicAdd(&g_rayhist[0][32 - __clz(st.acc->ray_leaves)], 1ull); atomicAdd(&g_rayhist[1][32 - __clz(st.acc->ray_nodes)], 1ull); } })
+                io.store(item, RT_ISANY ? fin : has, out, minT);
             }
             RT_STAT(st.acc->ray_leaves = 0; st.acc->ray_nodes = 0;)
             alive = false;
@@ -958,7 +965,8 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                         const uint32_t i = begin + (pb0 + strip % pnb) * 64u + (strip / pnb) * STRIP + within;
                         if (i < end) {
                             item = i;
-                            got = io.load(i, ro, rd, time, minT, has, out);
+                            if constexpr (MIXED) got = io.load(i, ro, rd, time, minT, has, out, lane_any);
+                            else got = io.load(i, ro, rd, time, minT, has, out);
                         }
                     }
                 }
@@ -990,7 +998,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         if (!refilled) break;
         }
         RT_STAT({ unsigned long long b = (c0 - st.acc->clk_start) / RT_HIST_TICKS; if (b >= RT_HIST_BINS) b = RT_HIST_BINS - 1;
-                  if (ANYHIT != RT_HIST_ANY) { st.acc->r_node_w = 0; st.acc->r_tri_w = 0; }
+                  if (ANY_ONLY != RT_HIST_ANY) { st.acc->r_node_w = 0; st.acc->r_tri_w = 0; }
                   if (st.acc->r_node_w) { atomicAdd(&g_hist[b][0], st.acc->r_node_w); atomicAdd(&g_hist[b][1], st.acc->r_node_l); }
                   if (st.acc->r_tri_w) { atomicAdd(&g_hist[b][2], st.acc->r_tri_w); atomicAdd(&g_hist[b][3], st.acc->r_tri_l); }
                   st.acc->r_node_w = st.acc->r_node_l = st.acc->r_tri_w = st.acc->r_tri_l = 0; })
@@ -998,3 +1006,4 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         RT_STAT({ const unsigned long long c5 = wall_clock64(); st.acc->t_sched += c1 - c0; st.acc->t_node += c2 - c1; st.acc->t_tri += c3 - c2; st.acc->t_big += c4 - c3; st.acc->t_trans += c5 - c4; })
     }
 }
+#undef RT_ISANY
