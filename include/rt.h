@@ -235,7 +235,9 @@ typedef struct rt_scene rt_scene;   /* opaque, library-owned, one per GPU */
 
 /* render flags for rt_scene_set_option(RT_OPT_FLAGS) */
 enum {
-    RT_FLAG_TIMING = 1u << 0   /* bracket kernels with HIP events -> rt_stats.ms_* */
+    RT_FLAG_TIMING = 1u << 0,  /* bracket kernels with HIP events -> rt_stats.ms_* */
+    RT_FLAG_SEPARATE_LAUNCHES = 1u << 1   /* trace the shadow rays of a generation and the child rays of the next
+                                             in two launches instead of one (diagnostic; same results) */
 };
 enum {
     RT_OPT_FLAGS          = 1,  /* bitmask of RT_FLAG_*                            */

@@ -746,17 +746,31 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         }
         if ((rc = tm.end())) return rc;
         const int grid_flat = 2048;
+        // closest(0); then per generation: shade(d), and ONE launch for what shade(d) produced — the shadow slots
+        // of generation d and the child rays of generation d + 1 are independent of each other (k_trace_mixed)
+        const bool merge = !(sc->opt_flags & RT_FLAG_SEPARATE_LAUNCHES);
+        if ((rc = tm.begin(TC_CLOSEST))) return rc;
+        k_trace_closest<<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, 0, spill, cand);
+        if ((rc = tm.end())) return rc;
         for (int d = 0; d <= D; d++) {
-            if ((rc = tm.begin(TC_CLOSEST))) return rc;
-            k_trace_closest<<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, spill, cand);
-            if ((rc = tm.end())) return rc;
             if ((rc = tm.begin(TC_SHADE))) return rc;
             k_shade<<<grid_flat, 256, 0, st>>>(sc->ds, P, ctl, d);
             k_advance<<<1, 64, 0, st>>>(ctl, P, d);
             if ((rc = tm.end())) return rc;
+            if (d < D && sc->n_point_lights && merge) {
+                if ((rc = tm.begin(TC_CLOSEST))) return rc;      // (timed under "closest": both kinds of ray)
+                k_trace_mixed<<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, d + 1, spill, cand);
+                if ((rc = tm.end())) return rc;
+                continue;
+            }
             if (sc->n_point_lights) {
                 if ((rc = tm.begin(TC_SHADOW))) return rc;
                 k_trace_shadow<<<sc->blocks_shadow, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, spill, cand);
+                if ((rc = tm.end())) return rc;
+            }
+            if (d < D) {
+                if ((rc = tm.begin(TC_CLOSEST))) return rc;
+                k_trace_closest<<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d + 1, spill, cand);
                 if ((rc = tm.end())) return rc;
             }
         }

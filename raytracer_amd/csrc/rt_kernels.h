@@ -475,6 +475,48 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_shadow(D
     if (traced && ww.lane == 0) atomicAdd(&ctl->rays_shadow, traced);
 }
 
+// One launch for two independent sets of rays that both come out of k_shade(g): the shadow slots of generation g
+// and the child rays of generation g + 1 (trace_persistent mode 2) — one end game instead of two per bounce.
+struct MixedIO {
+    ClosestIO c;
+    ShadowIO s;
+    uint32_t cbegin, n_c, sbegin;      // records [cbegin, cbegin + n_c), shadow slots from sbegin
+    __device__ __forceinline__ uint32_t first_blocks() const { return (n_c + 63u) / 64u; }
+    __device__ __forceinline__ uint32_t first_count() const { return n_c; }
+    __device__ __forceinline__ int load(uint32_t i, V3& o, V3& d, float& time, float& minT, bool& has, HitOut& h, bool& any) const {
+        const uint32_t pad = first_blocks() * 64u;
+        if (i < pad) { any = false; return c.load(cbegin + i, o, d, time, minT, has, h); }
+        any = true;
+        return s.load(sbegin + (i - pad), o, d, time, minT, has, h);
+    }
+    __device__ __forceinline__ void store(uint32_t i, bool verdict, const HitOut& h, float minT) const {
+        const uint32_t pad = first_blocks() * 64u;
+        if (i < pad) c.store(cbegin + i, verdict, h, minT);
+        else s.store(sbegin + (i - pad), verdict, h, minT);
+    }
+};
+
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_mixed(DScene S, Pool P, Control* ctl, int gen_shadow, int gen_closest, uint2* spill, uint4* cand) {
+    __shared__ TraceLds<RT_TRACE_BLOCK> s_lds;
+    WaveWork ww;
+    TraceStack st = make_stack(s_lds, spill, cand, ww);
+#ifdef RT_TRACE_STATS
+    TraceStatsAcc acc = {};
+    st.acc = &acc;
+    acc.clk_start = wall_clock64();
+#endif
+    const uint32_t cbegin = ctl->gstart[gen_closest], n_c = ctl->gstart[gen_closest + 1] - cbegin;
+    const uint32_t sbegin = ctl->sstart[gen_shadow], n_s = ctl->sstart[gen_shadow + 1] - sbegin;
+    MixedIO io{ClosestIO{S, P}, ShadowIO{S, P}, cbegin, n_c, sbegin};
+    unsigned long long traced = 0, traced_any = 0;   // wave-uniform
+    trace_persistent<2, true>(S, io, 0u, io.first_blocks() * 64u + n_s, ctl->cursor_closest, st, traced, &traced_any);
+    if (st.overflow) atomicOr(&ctl->overflow, (st.overflow & 48u) | ((st.overflow & ~48u) ? 4u : 0u));
+    if (ww.lane == 0) {
+        if (traced_any) atomicAdd(&ctl->rays_shadow, traced_any);
+        if (traced - traced_any) atomicAdd(gen_closest == 0 ? &ctl->rays_primary : &ctl->rays_secondary, traced - traced_any);
+    }
+}
+
 // ------------------------------------------------------------------- shading
 // Everything ApplyShading derives from (ray, hit point, normal, material) before
 // it needs child colours or shadow results (raytracer.cpp:1250-1345).

@@ -121,6 +121,8 @@ struct LaneMixedIO {
         if (L.req == OREQ_ANYHIT) { any = true; return LaneShadowIO{S, L, lane}.load(i, o, d, time, minT, has, h); }
         return 0;
     }
+    __device__ __forceinline__ uint32_t first_blocks() const { return 1u; }     // the 64 lanes' requests, item = lane
+    __device__ __forceinline__ uint32_t first_count() const { return 64u; }
     __device__ __forceinline__ void store(uint32_t i, bool verdict, const HitOut& h, float minT) const {
         if (L.req == OREQ_ANYHIT) LaneShadowIO{S, L, lane}.store(i, verdict, h, minT);
         else LaneClosestIO{S, L, lane}.store(i, verdict, h, minT);

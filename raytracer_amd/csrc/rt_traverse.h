@@ -324,7 +324,7 @@ __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int src) { return (ui
 //   (verdict = has / in-shadow).
 template <int MODE, bool LINGER, class IO>
 __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32_t end, uint32_t* cursor, TraceStack& st,
-                                 unsigned long long& traced) {
+                                 unsigned long long& traced, unsigned long long* traced_any = nullptr) {
     // MODE 0: closest hit, 1: any-hit, 2: mixed — every lane's item says which it is (rt_ordered.h, where the
     // lanes of a wave ask for both kinds at once); `lane_any` is then a per-lane value, otherwise a constant
     constexpr bool MIXED = MODE == 2;
@@ -382,7 +382,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
     // A large generation is cut into RT_PARTS contiguous partitions, each with a cursor of its own, and a
     // workgroup starts on partition blockIdx % RT_PARTS: the workgroups that share an XCD work on one part of
     // the image (of the record pool), so that XCD's L2 holds that part's share of the BVH instead of all of it.
-    const uint32_t parts = (LINGER && n_blocks >= RT_PARTS_MIN_BLOCKS) ? (uint32_t)RT_PARTS : 1u;
+    const uint32_t parts = (LINGER && !MIXED && n_blocks >= RT_PARTS_MIN_BLOCKS) ? (uint32_t)RT_PARTS : 1u;
     const uint32_t part0 = LINGER ? blockIdx.x % parts : 0u;
     uint32_t parts_done = 0;     // wave-uniform: partitions this wave knows to be drained
     uint32_t stale = 0;          // wave-uniform: rounds with idle lanes since the last refill
@@ -961,9 +961,28 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     // cursor value -> item: strip-interleaved over the partition's 64-item blocks (see above)
                     const uint32_t c = base + (uint32_t)__popcll(idle & lanes_below);
                     if (c < p_padded) {
-                        const uint32_t strip = c / STRIP, within = c % STRIP;
-                        const uint32_t i = begin + (pb0 + strip % pnb) * 64u + (strip / pnb) * STRIP + within;
-                        if (i < end) {
+                        uint32_t i;
+                        bool valid;
+                        if constexpr (MIXED) {
+                            // first the closest-hit items, strip-interleaved over their blocks; then the any-hit
+                            // items block by block (item ids: the first kind's padded count, then the second kind) —
+                            // the cheap any-hit rays are what is in flight when the cursor runs dry
+                            const uint32_t nb1 = io.first_blocks();
+                            if (c < nb1 * 64u) {
+                                const uint32_t strip = c / STRIP, within = c % STRIP;
+                                i = (strip % nb1) * 64u + (strip / nb1) * STRIP + within;
+                                valid = i < io.first_count();
+                            } else {
+                                i = c;
+                                valid = i < end;
+                            }
+                            i += begin;
+                        } else {
+                            const uint32_t strip = c / STRIP, within = c % STRIP;
+                            i = begin + (pb0 + strip % pnb) * 64u + (strip / pnb) * STRIP + within;
+                            valid = i < end;
+                        }
+                        if (valid) {
                             item = i;
                             if constexpr (MIXED) got = io.load(i, ro, rd, time, minT, has, out, lane_any);
                             else got = io.load(i, ro, rd, time, minT, has, out);
@@ -971,6 +990,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     }
                 }
                 traced += __popcll(__ballot(got != 0));
+                if (MIXED && traced_any) *traced_any += __popcll(__ballot(got != 0 && lane_any));
                 refilled = __any(got == 2);
                 if (got == 2) {
                     fin = false;
