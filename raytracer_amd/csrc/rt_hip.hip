@@ -18,6 +18,7 @@
 #include "rt.h"
 #include "rt_kernels.h"
 #include "rt_ordered.h"
+#include "rt_upload.h"
 
 namespace {
 
@@ -368,6 +369,10 @@ __global__ void __launch_bounds__(256) k_build_vnormals(const rt_vertex* __restr
     if (i < n) vn[i] = make_float4(vd[i].normal[0], vd[i].normal[1], vd[i].normal[2], 0.f);
 }
 
+#ifndef RT_COLLAPSE_MIN_NODES
+#define RT_COLLAPSE_MIN_NODES 8192   // mesh BVHs below this are collapsed on the host
+#endif
+
 // RT_UPLOAD_TIMING=1: phase times of rt_upload_scene on stderr
 struct PhaseClock {
     bool on = getenv("RT_UPLOAD_TIMING") != nullptr;
@@ -386,24 +391,98 @@ int build_mesh_level(rt_scene* sc, const rt_scene_desc* s) {
     std::vector<DNode4> nodes;
     std::vector<DBigLeaf> big;
 
-    // mesh BVHs: the node records are collapsed on the host (a sequential walk, a few ms per million triangles)
+    // mesh BVHs -> node records.  Large BVHs are collapsed on the device (rt_upload.h), small ones on the host;
+    // the records of BVH b follow those of BVH b - 1 in the node array either way.
+    const bool host_only = getenv("RT_UPLOAD_HOST_COLLAPSE") != nullptr;
     std::vector<BvhLayout> mesh_layout(s->n_mesh_bvhs);
     bool donate_ok = true;
+    size_t rec_cap = 0;
+    uint32_t max_dev_nodes = 0;
+    for (uint32_t b = 0; b < s->n_mesh_bvhs; b++) {
+        rec_cap += s->mesh_bvhs[b].node_count / 2 + 1;
+        if (!host_only && s->mesh_bvhs[b].node_count >= RT_COLLAPSE_MIN_NODES) max_dev_nodes = std::max(max_dev_nodes, s->mesh_bvhs[b].node_count);
+    }
+    if (rec_cap >= 0x7FFFFFF0u - 2ull * s->n_top_nodes || s->n_mesh_prims >= RT_LEAF_MAX_FIRST)
+        return fail(RT_ERR_UNSUPPORTED, "scene too large for the link encoding (2^26 leaf prims)");
+    int rc;
+    // the top level's records follow the meshes' in the same array: leave room for them (rt_update_scene grows it if needed)
+    if ((rc = sc->b_nodes.ensure((rec_cap + std::max<size_t>(1024, 2 * (size_t)s->n_top_nodes)) * sizeof(DNode4)))) return rc;
+    DevBuf d_ref, d_anc0, d_anc1, d_local, d_sums, d_word;
+    struct Release6 { DevBuf *b[6]; ~Release6() { for (DevBuf* x : b) x->release(); } } rel6{{&d_ref, &d_anc0, &d_anc1, &d_local, &d_sums, &d_word}};
+    if (max_dev_nodes) {
+        const size_t nb = (max_dev_nodes + RT_COLLAPSE_BLOCK - 1) / RT_COLLAPSE_BLOCK;
+        if ((rc = d_ref.ensure((size_t)s->n_mesh_nodes * sizeof(rt_bvh_node))) || (rc = d_anc0.ensure((size_t)max_dev_nodes * 4)) ||
+            (rc = d_anc1.ensure((size_t)max_dev_nodes * 4)) || (rc = d_local.ensure((size_t)max_dev_nodes * 4)) ||
+            (rc = d_sums.ensure(nb * 4)) || (rc = d_word.ensure(8)))
+            return rc;
+        HIPCHK(hipMemcpy(d_ref.p, s->mesh_nodes, (size_t)s->n_mesh_nodes * sizeof(rt_bvh_node), hipMemcpyHostToDevice));
+    }
+    uint32_t rec_count = 0;                     // records written (or pending in `nodes`) so far
+    uint32_t pending_base = 0;                  // device index of nodes[0]
+    auto flush_host_records = [&]() -> int {
+        if (!nodes.empty()) HIPCHK(hipMemcpy((DNode4*)sc->b_nodes.p + pending_base, nodes.data(), nodes.size() * sizeof(DNode4), hipMemcpyHostToDevice));
+        nodes.clear();
+        pending_base = rec_count;
+        return RT_OK;
+    };
     for (uint32_t b = 0; b < s->n_mesh_bvhs; b++) {
         const rt_mesh_bvh& mb = s->mesh_bvhs[b];
-        mesh_layout[b] = layout_bvh(s->mesh_nodes + mb.node_offset, mb.node_count, mb.prim_offset, false, nodes, big);
+        const rt_bvh_node* ref = s->mesh_nodes + mb.node_offset;
+        if (host_only || mb.node_count < RT_COLLAPSE_MIN_NODES) {
+            mesh_layout[b] = layout_bvh(ref, mb.node_count, mb.prim_offset, false, nodes, big, pending_base);
+            rec_count = pending_base + (uint32_t)nodes.size();
+            continue;
+        }
+        if ((rc = flush_host_records())) return rc;
+        const uint32_t n = mb.node_count, grid = (n + 255) / 256, nb = (n + RT_COLLAPSE_BLOCK - 1) / RT_COLLAPSE_BLOCK;
+        const rt_bvh_node* dref = (const rt_bvh_node*)d_ref.p + mb.node_offset;
+        uint32_t* anc[2] = {(uint32_t*)d_anc0.p, (uint32_t*)d_anc1.p};
+        uint32_t* word = (uint32_t*)d_word.p;
+        k_collapse_parents<<<grid, 256, 0, sc->stream>>>(dref, n, anc[0]);
+        int cur = 0;
+        bool converged = false;
+        for (int round = 0; round < 12 && !converged; round++) {      // depth <= 4096; the reference's own stack holds 64
+            const int jumps = round == 0 ? 6 : 1;
+            for (int j = 0; j < jumps; j++) {
+                HIPCHK(hipMemsetAsync(word, 0, 4, sc->stream));
+                k_collapse_jump<<<grid, 256, 0, sc->stream>>>(anc[cur], anc[cur ^ 1], n, word);
+                cur ^= 1;
+            }
+            uint32_t not_done = 1;
+            HIPCHK(hipMemcpyAsync(&not_done, word, 4, hipMemcpyDeviceToHost, sc->stream));
+            HIPCHK(hipStreamSynchronize(sc->stream));
+            converged = not_done == 0;
+        }
+        if (!converged) return fail(RT_ERR_INVALID, "mesh BVH %u is deeper than 4096 levels", b);
+        k_collapse_flag_scan<<<nb, RT_COLLAPSE_BLOCK, 0, sc->stream>>>(dref, anc[cur], n, (uint32_t*)d_local.p, (uint32_t*)d_sums.p);
+        k_collapse_scan_sums<<<1, RT_COLLAPSE_BLOCK, 0, sc->stream>>>((uint32_t*)d_sums.p, nb, word + 1);
+        k_collapse_emit<<<grid, 256, 0, sc->stream>>>(dref, (const uint32_t*)d_local.p, (const uint32_t*)d_sums.p, n, mb.prim_offset, rec_count,
+                                                      (DNode4*)sc->b_nodes.p);
+        uint32_t n_rec = 0;
+        HIPCHK(hipMemcpyAsync(&n_rec, word + 1, 4, hipMemcpyDeviceToHost, sc->stream));
+        HIPCHK(hipStreamSynchronize(sc->stream));
+        HIPCHK(hipGetLastError());
+        BvhLayout& L = mesh_layout[b];
+        std::memcpy(L.rmin, ref[0].bmin, 12);
+        std::memcpy(L.rmax, ref[0].bmax, 12);
+        for (uint32_t i = 0; i < n; i++)            // leaves beyond the 5-bit count: side table (sorted later)
+            if (ref[i].prim_count > 30) big.push_back(DBigLeaf{mb.prim_offset + (uint32_t)ref[i].left_or_first, (uint32_t)ref[i].prim_count});
+        if (ref[0].prim_count > 0) {
+            BvhBuilder4 tmp{ref, mb.prim_offset, false, nodes, big, 0};
+            const size_t nbig = big.size();
+            L.root_link = tmp.leaf_link(ref[0]);
+            big.resize(nbig);                       // (already listed by the loop above)
+        } else {
+            L.root_link = rec_count;
+        }
+        rec_count += n_rec;
+        pending_base = rec_count;
     }
-    pc.lap("mesh BVH layout (host)");
+    if ((rc = flush_host_records())) return rc;
+    pc.lap("mesh BVH collapse");
     for (uint32_t b = 0; b < s->n_mesh_bvhs; b++)
         if (!leaves_ascending(s->mesh_nodes + s->mesh_bvhs[b].node_offset, s->mesh_bvhs[b].node_count)) donate_ok = false;
     pc.lap("leaf order check (host)");
-    if (nodes.size() >= 0x7FFFFFF0u - 2ull * s->n_top_nodes || s->n_mesh_prims >= RT_LEAF_MAX_FIRST)
-        return fail(RT_ERR_UNSUPPORTED, "scene too large for the link encoding (2^26 leaf prims)");
-
-    int rc;
-    // the top level's records follow the meshes' in the same array: leave room for them (rt_update_scene grows it if needed)
-    if ((rc = sc->b_nodes.ensure((nodes.size() + std::max<size_t>(1024, 2 * (size_t)s->n_top_nodes)) * sizeof(DNode4)))) return rc;
-    if (!nodes.empty()) HIPCHK(hipMemcpy(sc->b_nodes.p, nodes.data(), nodes.size() * sizeof(DNode4), hipMemcpyHostToDevice));
     // triangle records, shading records and vertex normals: gathered on the device from the caller's arrays
     if ((rc = sc->b_tris.ensure(std::max<size_t>(s->n_mesh_prims, 1) * sizeof(DTri))) ||
         (rc = sc->b_tri_shade.ensure(std::max<size_t>(s->n_mesh_prims, 1) * sizeof(DTriShade))) ||
@@ -441,7 +520,7 @@ int build_mesh_level(rt_scene* sc, const rt_scene_desc* s) {
         std::memcpy(M.roots[b].rmax, mesh_layout[b].rmax, 12);
     }
     M.big = big;
-    M.n_node_records = (uint32_t)nodes.size();
+    M.n_node_records = rec_count;
     M.n_mesh_bvhs = s->n_mesh_bvhs; M.n_mesh_nodes = s->n_mesh_nodes; M.n_mesh_prims = s->n_mesh_prims;
     M.n_faces = s->n_faces; M.n_vertices = s->n_vertices;
     M.hash = mesh_hash(s);

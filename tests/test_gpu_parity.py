@@ -282,3 +282,27 @@ def test_degenerate_scenes_vs_oracle(rt):
     cases.append(s)
     for spec in cases:
         _vs_oracle(rt, spec)
+
+
+@pytest.mark.gpu
+def test_device_side_bvh_collapse_equals_host_collapse(rt, tmp_path):
+    """rt_upload_scene collapses large mesh BVHs into node records on the device (rt_upload.h: parent links,
+    pointer jumping for the depth parity, scan, emit) and small ones on the host; RT_UPLOAD_HOST_COLLAPSE=1 forces
+    the host walk for all.  Frames and hit ids must not depend on which one built the records (the full-size
+    mesh and a scene that mixes both kinds of BVH)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    specs = ["mesh:709:960:540", "inst:200:640:360", "golden:hw2_two_berserkers"]
+    outs = []
+    for host in (False, True):
+        path = str(tmp_path / f"collapse_{int(host)}.npz")
+        env = dict(os.environ)
+        env.pop("RT_UPLOAD_HOST_COLLAPSE", None)
+        if host:
+            env["RT_UPLOAD_HOST_COLLAPSE"] = "1"
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_render_npz.py"), path] + specs,
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+    for k in outs[0].files:
+        assert (outs[0][k] == outs[1][k]).all(), k
