@@ -1,8 +1,8 @@
 // rt_traverse.h — wave64 two-level BVH traversal (closest-hit and any-hit).
 //
 // Restates, with the reference's exact visiting order and culling rules,
-//   IntersectTopBVH   raytracer.cpp:527-756     (closest hit, ANYHIT = false)
-//   InShadow's loop   raytracer.cpp:1030-1243   (first accepted hit, ANYHIT = true)
+//   IntersectTopBVH   raytracer.cpp:527-756     (closest hit, mode 0)
+//   InShadow's loop   raytracer.cpp:1030-1243   (first accepted hit, mode 1; mode 2: per lane either of the two)
 //   IntersectMeshBVH  raytracer.cpp:758-811
 //   IntersectAABB     raytracer.cpp:815-894
 //   IntersectsTriangle_Bary raytracer.cpp:896-947, IntersectSphere :949-980
@@ -34,11 +34,11 @@
 //     monotonicity it passes whenever L's does), and traversing with a stale,
 //     larger minT can only add candidates, which that re-check removes again.
 //     It lifts SIMD utilisation of the node loop from 21 % to ~55 %.
-//   * a direction component that is exactly 0 takes 1/d = +inf instead of the
-//     reference's separate branch (raytracer.cpp:834-838): (b-o)*inf is -inf,
-//     NaN or +inf for o inside, on, or outside a face, and NaN operands are
-//     ignored by the reference's own std::max/std::min argument order, which
-//     reproduces "miss iff o < min or o > max" exactly, branch-free.
+//   * the box test is branch-free for rays whose three 1/d are finite (no slab product can be a NaN then; a
+//     node record holds the four slots' planes by axis and a lane loads the planes its ray meets first / last,
+//     so the slab distances come out ordered without the reference's compare-and-swap); rays with an infinite
+//     1/d (d == 0, or 1/d overflowing) take the reference's branches literally — rt_box.h, which is also
+//     compiled for the host and compared with the oracle (tests/box_logic.cpp).
 //   * both BVH levels run in ONE loop (a lane switches its active ray to object
 //     space and back), so lanes at different levels share the node-fetch /
 //     box-test instructions instead of serialising nested loops.
@@ -281,8 +281,8 @@ __device__ __forceinline__ bool is_big_leaf_link(uint32_t link) { return link >=
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 
-// The persistent trace loop of one wave: FindClosestHit's BVH part (ANYHIT = false)
-// or InShadow's (ANYHIT = true) for the items [begin, end) of a generation.
+// The persistent trace loop of one wave: FindClosestHit's BVH part (MODE 0), InShadow's (MODE 1), or both
+// at once with the kind given per item (MODE 2: k_trace_mixed, k_pixel_ordered), for the items [begin, end).
 //
 // Scheduling.  The 64 lanes are 64 ray slots.
 //  * Refill: a lane whose ray is finished stores its result and goes idle; when
@@ -310,8 +310,7 @@ __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int src) { return (ui
 //    raytracer.cpp:247-262, and the left child is visited first) with the reference's
 //    rule: skip if minT culls the leaf box, accept if t < minT.  That is the
 //    reference's result exactly; what changes is that one long ray is traced by many
-//    lanes (the slowest ray of the 1M-triangle frame takes ~1000 sequential steps,
-//    longer than the rest of the kernel).  A ray with more than RT_CAND_MAX candidates
+//    lanes.  A ray with more than RT_CAND_MAX candidates
 //    re-traverses the mesh alone.  Bounded: a wave gives up after RT_ROUND_CAP rounds,
 //    an owner after RT_WAIT_ROUNDS_MAX rounds of waiting (reported as errors).
 //  * The node phase of a round ends when no lane can walk on — or when only a few
@@ -321,7 +320,9 @@ __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int src) { return (ui
 //   included, raytracer.cpp:423-435 / :1022-1028) and returns 2, or stores a final
 //   result itself and returns 1 (a ray that needs no traversal) or 0 (no ray);
 //   IO::store(item, verdict, out, minT) stores the result of a traversed ray
-//   (verdict = has / in-shadow).
+//   (verdict = has / in-shadow).  MODE 2: load has one more argument, bool& any (set to the item's kind), and
+//   the IO tells how many 64-item blocks of closest-hit items precede the any-hit items (first_blocks,
+//   first_count): the cursor hands out the former strip-interleaved, then the latter block by block.
 template <int MODE, bool LINGER, class IO>
 __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32_t end, uint32_t* cursor, TraceStack& st,
                                  unsigned long long& traced, unsigned long long* traced_any = nullptr) {
