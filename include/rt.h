@@ -241,8 +241,9 @@ enum {
 };
 enum {
     RT_OPT_FLAGS          = 1,  /* bitmask of RT_FLAG_*                            */
-    RT_OPT_POOL_RECORDS   = 2,  /* capacity of the ray-record pool (records)       */
-    RT_OPT_CHUNK_SAMPLES  = 3   /* max pixel-samples started per chunk             */
+    RT_OPT_POOL_RECORDS   = 2,  /* upper bound of the ray-record pool (records, ~104 B each; default 256 M):
+                                   a render allocates four records per sample of its largest chunk, up to this */
+    RT_OPT_CHUNK_SAMPLES  = 3   /* max pixel-samples started per chunk (default 64 M) */
 };
 
 /* Number of HIP devices visible to this process (<0: rt_status). */

@@ -113,8 +113,8 @@ struct rt_scene {
 
     // options
     uint64_t opt_flags = 0;
-    uint64_t opt_pool_records = 16ull << 20;
-    uint64_t opt_chunk_samples = 8ull << 20;
+    uint64_t opt_pool_records = 256ull << 20;    // upper bound; a render allocates what it needs (ensure_pool)
+    uint64_t opt_chunk_samples = 64ull << 20;
 
     // timing events
     struct Ev { hipEvent_t a, b; int cat; };
@@ -670,9 +670,11 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
     return rc ? rc : build_top_level(sc, s);
 }
 
-int ensure_pool(rt_scene* sc) {
-    const size_t cap = (size_t)sc->opt_pool_records;
-    if (sc->pool.cap_records == cap && sc->b_ray0.p) return RT_OK;
+// The record pool grows to what a render needs, up to RT_OPT_POOL_RECORDS (27 GB at its default of 256 M records:
+// sized for 288 GB of HBM — large pools mean few chunks, hence few launches with an end game each).
+int ensure_pool(rt_scene* sc, uint64_t want_records) {
+    const size_t cap = (size_t)std::min<uint64_t>(sc->opt_pool_records, std::max<uint64_t>(want_records, 1ull << 16));
+    if (sc->pool.cap_records >= cap && sc->pool.cap_records <= sc->opt_pool_records && sc->b_ray0.p) return RT_OK;
     const size_t lights = std::max<uint32_t>(sc->n_point_lights, 1);
     const size_t cap_sh = cap * std::min<size_t>(lights, 4);
     int rc;
@@ -739,8 +741,7 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         return RT_OK;
     }
     const int D = sc->has_reflective ? depth : 0;   // without reflective materials no child ray is ever spawned
-    int rc = sc->needs_sequential_rng ? RT_OK : ensure_pool(sc);
-    if (rc) return rc;
+    int rc;
     if ((rc = sc->b_ctl.ensure(sizeof(Control)))) return rc;
     Control* ctl = (Control*)sc->b_ctl.p;
     // per-wave scratch of the trace loops, sized for the largest resident grid of any kernel that runs them
@@ -769,6 +770,12 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
     const int tiles_per_row = (w + 7) / 8, tile_rows_all = (h + 7) / 8;
     const int tile_rows = row_part < tile_rows_all ? (tile_rows_all - row_part + row_parts - 1) / row_parts : 0;
     const uint32_t total_tiles = (uint32_t)tiles_per_row * tile_rows;
+    if (!sc->needs_sequential_rng) {
+        // records: one per primary sample, and with child rays about twice that (a chunk that overflows is redone
+        // with half the pixels): room for four per sample of the largest chunk
+        const uint64_t chunk = std::min<uint64_t>((uint64_t)total_tiles * 64 * N, sc->opt_chunk_samples);
+        if ((rc = ensure_pool(sc, D > 0 ? 4 * chunk : chunk))) return rc;
+    }
     const Pool& P = sc->pool;
     // tiles per chunk: bounded by the chunk option, the record pool and the shadow pool
     uint64_t max_samples = std::min<uint64_t>(sc->opt_chunk_samples, D > 0 ? P.cap_records / 2 : P.cap_records);
@@ -776,8 +783,9 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
     uint32_t tiles_per_chunk = (uint32_t)std::max<uint64_t>(1, max_samples / (64ull * N));
     if (!sc->needs_sequential_rng && (uint64_t)tiles_per_chunk * 64 * N > P.cap_records) return fail(RT_ERR_OVERFLOW, "record pool too small for one 8x8 tile at %d spp", N);
 
-    uint32_t chunks = 0;
+    uint32_t chunks = 0, retries = 0;
     uint64_t peak = 0;
+    unsigned long long good_rays[3] = {0, 0, 0};     // ray counters after the last chunk that was kept
     uint32_t tile = 0;
     if (sc->needs_sequential_rng) {
         // Shading draws random numbers (glossy materials, area lights): one lane per pixel walks the recursion
@@ -870,8 +878,13 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
             if (sc->h_ctl->overflow & 3u) {
                 if (tiles_per_chunk == 1) return fail(RT_ERR_OVERFLOW, "ray pool too small for one 8x8 tile; raise RT_OPT_POOL_RECORDS");
                 tiles_per_chunk = std::max(1u, tiles_per_chunk / 2);
-                continue;   // redo this chunk with fewer pixels (counters of the failed try stay: stats are upper bounds then)
+                // redo this chunk with fewer pixels; the rays of the failed try do not count
+                HIPCHK(hipMemcpyAsync(&ctl->rays_primary, good_rays, sizeof(good_rays), hipMemcpyHostToDevice, st));
+                HIPCHK(hipStreamSynchronize(st));
+                retries++;
+                continue;
             }
+            good_rays[0] = sc->h_ctl->rays_primary; good_rays[1] = sc->h_ctl->rays_secondary; good_rays[2] = sc->h_ctl->rays_shadow;
             peak = std::max<uint64_t>(peak, sc->h_ctl->n_records);
         } else {
             peak = std::max<uint64_t>(peak, n_primary);
@@ -951,7 +964,7 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         stats->rays_secondary = sc->h_ctl->rays_secondary;
         stats->rays_shadow = sc->h_ctl->rays_shadow;
         stats->records_peak = peak;
-        stats->chunks = chunks;
+        stats->chunks = chunks - retries;     // chunks kept (a chunk that overflowed its pool is redone smaller)
         HIPCHK(hipEventElapsedTime(&stats->ms_total, ev_total_a, ev_total_b));
         (void)hipEventDestroy(ev_total_a);
         (void)hipEventDestroy(ev_total_b);

@@ -1,0 +1,20 @@
+import sys, time
+sys.path.insert(0, '/root/repo')
+import torch
+from raytracer_amd import DeviceScene, Stats, RT_OPT_FLAGS, RT_FLAG_TIMING, RT_OPT_POOL_RECORDS, RT_OPT_CHUNK_SAMPLES, scenes
+hs = scenes.instanced_scene(709, 3840, 2160, num_samples=16).build()
+cam = hs.camera(0)
+fb = torch.zeros((cam.image_height, cam.image_width, 3), dtype=torch.uint8, device="cuda")
+for pool, chunk in ((16 << 20, 8 << 20), (64 << 20, 32 << 20), (128 << 20, 64 << 20), (256 << 20, 133 << 20)):
+    ds = DeviceScene(hs, 0)
+    ds.set_option(RT_OPT_FLAGS, RT_FLAG_TIMING)
+    ds.set_option(RT_OPT_POOL_RECORDS, pool)
+    ds.set_option(RT_OPT_CHUNK_SAMPLES, chunk)
+    best = None
+    for it in range(2):
+        st = Stats()
+        ds.render_device(cam, 0, 0, cam.image_width, cam.image_height, fb.data_ptr(), cam.image_width * 3, stats=st)
+        if best is None or st.ms_total < best.ms_total: best = st
+    rays = best.rays_primary + best.rays_secondary + best.rays_shadow
+    print(f"pool {pool>>20}M chunk {chunk>>20}M: {best.ms_total:.1f} ms {rays/best.ms_total/1e3:.1f} Mrays/s chunks {best.chunks} peak {best.records_peak}", flush=True)
+    ds.close()
