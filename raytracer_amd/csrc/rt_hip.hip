@@ -110,6 +110,8 @@ struct rt_scene {
     DevBuf b_ray0, b_ray1, b_hit0, b_hit1, b_nrm, b_link, b_color, b_shadow_rec, b_shadow_lit;
     DevBuf b_ctl, b_spill, b_cand, b_mt, b_frames, b_fb, b_hits;
     Control* h_ctl = nullptr;   // pinned
+    void* h_stage = nullptr;    // pinned staging for rt_render_tile's host outputs
+    size_t h_stage_bytes = 0;
 
     // options
     uint64_t opt_flags = 0;
@@ -1091,10 +1093,24 @@ int rt_render_tile(rt_scene* s, const rt_camera_desc* cam, int x0, int y0, int t
     rc = render_impl(s, cam, x0, y0, tile_w, tile_h, 1, 0, (uint8_t*)s->b_fb.p, (size_t)tile_w * 3, hit_id_out ? (uint32_t*)s->b_hits.p : nullptr,
                      stats, s->stream);
     if (rc) return rc;
-    HIPCHK(hipMemcpy2DAsync(rgb_out, rgb_row_stride_bytes, s->b_fb.p, (size_t)tile_w * 3, (size_t)tile_w * 3, tile_h,
-                            hipMemcpyDeviceToHost, s->stream));
-    if (hit_id_out) HIPCHK(hipMemcpyAsync(hit_id_out, s->b_hits.p, hit_bytes, hipMemcpyDeviceToHost, s->stream));
+    // device -> pinned staging (one contiguous copy at PCIe rate) -> the caller's rows; a 2-D copy straight into
+    // pageable memory took 7.5 ms for a 1920x1080 frame, this takes well under 1 ms
+    const size_t need = fb_bytes + (hit_id_out ? hit_bytes : 0);
+    if (s->h_stage_bytes < need) {
+        if (s->h_stage) (void)hipHostFree(s->h_stage);
+        s->h_stage = nullptr;
+        s->h_stage_bytes = 0;
+        HIPCHK(hipHostMalloc(&s->h_stage, need));
+        s->h_stage_bytes = need;
+    }
+    uint8_t* stage = (uint8_t*)s->h_stage;
+    HIPCHK(hipMemcpyAsync(stage, s->b_fb.p, fb_bytes, hipMemcpyDeviceToHost, s->stream));
+    if (hit_id_out) HIPCHK(hipMemcpyAsync(stage + fb_bytes, s->b_hits.p, hit_bytes, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    const size_t row = (size_t)tile_w * 3;
+    if (rgb_row_stride_bytes == row) std::memcpy(rgb_out, stage, fb_bytes);
+    else for (int y = 0; y < tile_h; y++) std::memcpy(rgb_out + (size_t)y * rgb_row_stride_bytes, stage + (size_t)y * row, row);
+    if (hit_id_out) std::memcpy(hit_id_out, stage + fb_bytes, hit_bytes);
     return RT_OK;
 }
 
@@ -1128,6 +1144,7 @@ void rt_free_scene(rt_scene* s) {
     for (auto& e : s->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
+    if (s->h_stage) (void)hipHostFree(s->h_stage);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
