@@ -478,6 +478,11 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
 #undef OFR_U
     if (st.overflow) atomicOr(&ctl->overflow, (st.overflow & 48u) | ((st.overflow & ~48u) ? 4u : 0u));
     if (L.bad_item) atomicOr(&ctl->overflow, 8u);
+#ifdef RT_TRACE_STATS
+    atomicAdd(&ctl->dbg[0], acc.wave_node_steps); atomicAdd(&ctl->dbg[1], acc.lane_node_steps);
+    atomicAdd(&ctl->dbg[2], acc.wave_tri_steps); atomicAdd(&ctl->dbg[3], acc.lane_tri_steps);
+    atomicAdd(&ctl->dbg[4], acc.wave_outer); atomicAdd(&ctl->dbg[5], n_primary + n_secondary + n_shadow);
+#endif
     if (n_primary) atomicAdd(&ctl->rays_primary, n_primary);
     if (n_secondary) atomicAdd(&ctl->rays_secondary, n_secondary);
     if (n_shadow) atomicAdd(&ctl->rays_shadow, n_shadow);
