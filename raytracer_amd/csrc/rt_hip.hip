@@ -757,6 +757,7 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
 
     const bool want_sync = stats != nullptr || (sc->opt_flags & RT_FLAG_TIMING) || D > 0 || sc->needs_sequential_rng;
     Timer tm{sc, st, (sc->opt_flags & RT_FLAG_TIMING) != 0};
+    const bool near = (sc->opt_flags & RT_FLAG_NEAR_FIRST) != 0;   // non-parity visiting order (rt.h)
     HIPCHK(hipMemsetAsync(ctl, 0, sizeof(Control), st));
 
     hipEvent_t ev_total_a = nullptr, ev_total_b = nullptr;
@@ -811,7 +812,8 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         A.tri_shade = sc->ds.tri_shade;
         if (grid > 0) {
             if ((rc = tm.begin(TC_CLOSEST))) return rc;
-            k_pixel_ordered<<<grid, RT_ORDERED_BLOCK, 0, st>>>(sc->ds, A, ctl, spill, cand);
+            if (near) k_pixel_ordered<true><<<grid, RT_ORDERED_BLOCK, 0, st>>>(sc->ds, A, ctl, spill, cand);
+            else k_pixel_ordered<false><<<grid, RT_ORDERED_BLOCK, 0, st>>>(sc->ds, A, ctl, spill, cand);
             if ((rc = tm.end())) return rc;
             HIPCHK(hipGetLastError());
         }
@@ -839,7 +841,8 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         // of generation d and the child rays of generation d + 1 are independent of each other (k_trace_mixed)
         const bool merge = !(sc->opt_flags & RT_FLAG_SEPARATE_LAUNCHES);
         if ((rc = tm.begin(TC_CLOSEST))) return rc;
-        k_trace_closest<<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, 0, spill, cand);
+        if (near) k_trace_closest<true><<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, 0, spill, cand);
+        else k_trace_closest<false><<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, 0, spill, cand);
         if ((rc = tm.end())) return rc;
         for (int d = 0; d <= D; d++) {
             if ((rc = tm.begin(TC_SHADE))) return rc;
@@ -848,7 +851,8 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
             if ((rc = tm.end())) return rc;
             if (d < D && sc->n_point_lights && merge) {
                 if ((rc = tm.begin(TC_CLOSEST))) return rc;      // (timed under "closest": both kinds of ray)
-                k_trace_mixed<<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, d + 1, spill, cand);
+                if (near) k_trace_mixed<true><<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, d + 1, spill, cand);
+                else k_trace_mixed<false><<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, d + 1, spill, cand);
                 if ((rc = tm.end())) return rc;
                 continue;
             }
@@ -859,7 +863,8 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
             }
             if (d < D) {
                 if ((rc = tm.begin(TC_CLOSEST))) return rc;
-                k_trace_closest<<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d + 1, spill, cand);
+                if (near) k_trace_closest<true><<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d + 1, spill, cand);
+                else k_trace_closest<false><<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d + 1, spill, cand);
                 if ((rc = tm.end())) return rc;
             }
         }
@@ -1024,11 +1029,11 @@ int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out) {
     // persistent grids: as many workgroups as are resident at once (RT_TRACE_BLOCKS_PER_CU caps it, for occupancy experiments)
     int per_cu = 0, cap = 8;
     if (const char* e = getenv("RT_TRACE_BLOCKS_PER_CU")) cap = std::max(1, std::min(8, atoi(e)));
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest, RT_TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest<false>, RT_TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     sc->blocks_closest = sc->n_cu * std::min(per_cu, cap);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_shadow, RT_TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     sc->blocks_shadow = sc->n_cu * std::min(per_cu, cap);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pixel_ordered, RT_ORDERED_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pixel_ordered<false>, RT_ORDERED_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     sc->blocks_ordered = sc->n_cu * std::min(per_cu, cap);
     *out = sc;
     return RT_OK;

@@ -401,6 +401,7 @@ struct ClosestIO {
     }
 };
 
+template <bool NEAR>
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_closest(DScene S, Pool P, Control* ctl, int gen, uint2* spill, uint4* cand) {
     __shared__ TraceLds<RT_TRACE_BLOCK> s_lds;
     WaveWork ww;
@@ -414,7 +415,7 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_closest(
 #endif
     unsigned long long traced = 0;   // wave-uniform
     ClosestIO io{S, P};
-    trace_persistent<false, true>(S, io, begin, end, ctl->cursor_closest, st, traced);
+    trace_persistent<0, true, NEAR>(S, io, begin, end, ctl->cursor_closest, st, traced);
     if (st.overflow) atomicOr(&ctl->overflow, (st.overflow & 48u) | ((st.overflow & ~48u) ? 4u : 0u));
 #ifdef RT_TRACE_STATS
 #ifndef RT_STATS_SHADOW
@@ -467,7 +468,7 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_shadow(D
 #endif
     unsigned long long traced = 0;
     ShadowIO io{S, P};
-    trace_persistent<true, true>(S, io, begin, end, ctl->cursor_shadow, st, traced);
+    trace_persistent<1, true, false>(S, io, begin, end, ctl->cursor_shadow, st, traced);
 #if defined(RT_TRACE_STATS) && defined(RT_STATS_SHADOW)
     report_trace_stats(ctl, acc, traced, clk_start, st, ww);
 #endif
@@ -496,6 +497,7 @@ struct MixedIO {
     }
 };
 
+template <bool NEAR>
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_mixed(DScene S, Pool P, Control* ctl, int gen_shadow, int gen_closest, uint2* spill, uint4* cand) {
     __shared__ TraceLds<RT_TRACE_BLOCK> s_lds;
     WaveWork ww;
@@ -509,7 +511,7 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_mixed(DS
     const uint32_t sbegin = ctl->sstart[gen_shadow], n_s = ctl->sstart[gen_shadow + 1] - sbegin;
     MixedIO io{ClosestIO{S, P}, ShadowIO{S, P}, cbegin, n_c, sbegin};
     unsigned long long traced = 0, traced_any = 0;   // wave-uniform
-    trace_persistent<2, true>(S, io, 0u, io.first_blocks() * 64u + n_s, ctl->cursor_closest, st, traced, &traced_any);
+    trace_persistent<2, true, NEAR>(S, io, 0u, io.first_blocks() * 64u + n_s, ctl->cursor_closest, st, traced, &traced_any);
     if (st.overflow) atomicOr(&ctl->overflow, (st.overflow & 48u) | ((st.overflow & ~48u) ? 4u : 0u));
     if (ww.lane == 0) {
         if (traced_any) atomicAdd(&ctl->rays_shadow, traced_any);

@@ -146,6 +146,7 @@ struct OrderedArgs {
 #ifndef RT_ORDERED_MIN_BLOCKS
 #define RT_ORDERED_MIN_BLOCKS 3  // workgroups per CU the register budget is set for
 #endif
+template <bool NEAR>
 __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pixel_ordered(DScene S, OrderedArgs A, Control* ctl, uint2* spill, uint4* cand) {
     __shared__ TraceLds<RT_ORDERED_BLOCK> s_lds;
     uint32_t* s_cursor = s_lds.cursor;
@@ -454,13 +455,13 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
                 if (ww.lane == 0) s_cursor[ww.wave] = 0;
                 LaneClosestIO io{S, L, ww.lane};
                 unsigned long long traced = 0;
-                trace_persistent<0, false>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
+                trace_persistent<0, false, NEAR>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
             }
             if (__any(L.req == OREQ_ANYHIT)) {
                 if (ww.lane == 0) s_cursor[ww.wave] = 0;
                 LaneShadowIO io{S, L, ww.lane};
                 unsigned long long traced = 0;
-                trace_persistent<1, false>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
+                trace_persistent<1, false, false>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
             }
 #else
             // closest-hit and any-hit requests share one loop: all lanes with a request are busy in it together,
@@ -469,7 +470,7 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
                 if (ww.lane == 0) s_cursor[ww.wave] = 0;
                 LaneMixedIO io{S, L, ww.lane};
                 unsigned long long traced = 0;
-                trace_persistent<2, false>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
+                trace_persistent<2, false, NEAR>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
             }
 #endif
         }

@@ -323,7 +323,7 @@ __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int src) { return (ui
 //   (verdict = has / in-shadow).  MODE 2: load has one more argument, bool& any (set to the item's kind), and
 //   the IO tells how many 64-item blocks of closest-hit items precede the any-hit items (first_blocks,
 //   first_count): the cursor hands out the former strip-interleaved, then the latter block by block.
-template <int MODE, bool LINGER, class IO>
+template <int MODE, bool LINGER, bool NEAR, class IO>
 __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32_t end, uint32_t* cursor, TraceStack& st,
                                  unsigned long long& traced, unsigned long long* traced_any = nullptr) {
     // MODE 0: closest hit, 1: any-hit, 2: mixed — every lane's item says which it is (rt_ordered.h, where the
@@ -585,6 +585,33 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     const bool h1 = hit4[1] & (lk.y != RT_LINK_DONE);
                     const bool h2 = hit4[2] & (lk.z != RT_LINK_DONE);
                     const bool h3 = hit4[3] & (lk.w != RT_LINK_DONE);
+                    if constexpr (NEAR && !ANY_ONLY) if (in_mesh) {
+                        // Non-parity order (RT_FLAG_NEAR_FIRST), inside a mesh BVH only: the hit slots are visited by
+                        // increasing entry distance instead of in the reference's slot order, so the bound shrinks
+                        // early and more of the later boxes are culled.  All triangles of a mesh are tested against
+                        // one bound in one space, so the closest hit is the same set minimum and only candidates with
+                        // equal t can come out differently.  The top level keeps the reference's order: there the
+                        // bound is carried between object spaces through a Q_rsqrt-normalised direction
+                        // (raytracer.cpp:572-580), and which of two nearby objects wins depends on the order.
+                        const float INF = __builtin_inff();
+                        float k0 = h0 ? t0 : INF, k1 = h1 ? t1 : INF, k2 = h2 ? t2 : INF, k3 = h3 ? t3 : INF;
+                        uint32_t l0 = lk.x, l1 = lk.y, l2 = lk.z, l3 = lk.w;
+#define RT_CSWAP(ka, la, kb, lb) { const bool s_ = ka > kb; const float kl_ = fminf(ka, kb), kh_ = fmaxf(ka, kb); const uint32_t ll_ = s_ ? lb : la, lh_ = s_ ? la : lb; ka = kl_; kb = kh_; la = ll_; lb = lh_; }
+                        RT_CSWAP(k0, l0, k1, l1) RT_CSWAP(k2, l2, k3, l3) RT_CSWAP(k0, l0, k2, l2) RT_CSWAP(k1, l1, k3, l3) RT_CSWAP(k1, l1, k2, l2)
+#undef RT_CSWAP
+                        if (!__any(st.sp + 3 > RT_STACK_LDS)) {
+                            if (k3 < INF) st.push_lds(l3, k3);
+                            if (k2 < INF) st.push_lds(l2, k2);
+                            if (k1 < INF) st.push_lds(l1, k1);
+                        } else {
+                            if (k3 < INF) st.push(l3, k3);
+                            if (k2 < INF) st.push(l2, k2);
+                            if (k1 < INF) st.push(l1, k1);
+                        }
+                        if (k0 < INF) { cur = l0; cur_t = k0; }
+                        else cur = st.pop(tmax, cur_t);
+                        continue;
+                    }
                     // visit order = slot order: the first hit slot is next, the later ones are
                     // pushed last-first so that they pop in order
                     const bool p1 = h1 & h0, p2 = h2 & (h0 | h1), p3 = h3 & (h0 | h1 | h2);

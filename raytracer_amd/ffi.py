@@ -13,6 +13,7 @@ RT_KIND_MESH, RT_KIND_TRIANGLE, RT_KIND_SPHERE, RT_KIND_PLANE = 0, 1, 2, 3
 RT_MAT_NONE, RT_MAT_MIRROR, RT_MAT_CONDUCTOR, RT_MAT_DIELECTRIC = 0, 1, 2, 3
 RT_FLAG_TIMING = 1
 RT_FLAG_SEPARATE_LAUNCHES = 2
+RT_FLAG_NEAR_FIRST = 4        # non-parity visiting order, see include/rt.h
 RT_UPDATE_VERIFY_MESHES = 1
 RT_OPT_FLAGS, RT_OPT_POOL_RECORDS, RT_OPT_CHUNK_SAMPLES = 1, 2, 3
 

@@ -306,3 +306,51 @@ def test_device_side_bvh_collapse_equals_host_collapse(rt, tmp_path):
         outs.append(np.load(path))
     for k in outs[0].files:
         assert (outs[0][k] == outs[1][k]).all(), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GOLD)
+def test_near_first_mode_meets_the_north_star_tolerance_on_reference_scenes(rt, name):
+    """RT_FLAG_NEAR_FIRST (include/rt.h) is the one NON-PARITY mode of the library: closest-hit rays visit the
+    children of a BVH node nearest first instead of in the reference's left-then-right order (raytracer.cpp:749-753,
+    802-806).  It is off by default and not held to byte-exactness, but it must stay inside the north_star's
+    tolerance against the reference's own renders: primary hit ids equal on >= 99.99 % of pixels, colours within
+    1 LSB on >= 99.9 %."""
+    hs = util.golden_scene(name)
+    cam = hs.camera(0)
+    ds = rt.DeviceScene(hs, 0)
+    ds.set_option(rt.RT_OPT_FLAGS, rt.RT_FLAG_NEAR_FIRST)
+    tile = util.golden_tile(name) or (0, 0, cam.image_width, cam.image_height)
+    rgb, hits = ds.render(cam, *tile, want_hits=True)
+    ds.close()
+    st = util.image_stats(rgb, util.golden_image(name))
+    ok = util.hit_ids_match(hits, util.golden_hits(name))
+    print(f"near-first {name}: hit ids {ok.mean():.6f} exact {st['exact']:.6f} within1 {st['within1']:.6f}")
+    assert ok.mean() >= 0.9999, f"hit-id agreement {ok.mean()}"
+    assert st["within1"] >= 0.999, st
+
+
+@pytest.mark.gpu
+def test_near_first_mode_vs_exact_mode_on_synthetic_meshes(rt):
+    """Same mode on the bench's scene family at a size the test suite affords (the full-size figures are in
+    bench.py's `near_first` object): against the exact mode of the same library, same tolerances; the ray counts
+    of the primary generation must agree exactly, and the mode must leave no trace on the next exact render."""
+    for spec in (rt.scenes.mesh_scene(grid=256, width=960, height=540),
+                 rt.scenes.instanced_scene(grid=128, width=640, height=360),
+                 rt.scenes.glossy_area_scene(grid=48, width=320, height=200, num_samples=4)):
+        hs = spec.build()
+        cam = hs.camera(0)
+        ds = rt.DeviceScene(hs, 0)
+        s0, s1 = rt.Stats(), rt.Stats()
+        rgb0, hits0 = ds.render(cam, want_hits=True, stats=s0)
+        ds.set_option(rt.RT_OPT_FLAGS, rt.RT_FLAG_NEAR_FIRST)
+        rgb1, hits1 = ds.render(cam, want_hits=True, stats=s1)
+        ds.set_option(rt.RT_OPT_FLAGS, 0)
+        rgb2, hits2 = ds.render(cam, want_hits=True)
+        ds.close()
+        same = (hits0.reshape(-1, 2) == hits1.reshape(-1, 2)).all(axis=1)
+        d = np.abs(rgb0.astype(np.int16) - rgb1.astype(np.int16)).max(axis=-1)
+        print(f"near-first {spec.name}: hit ids {same.mean():.6f} exact {(d == 0).mean():.6f} within1 {(d <= 1).mean():.6f}")
+        assert same.mean() >= 0.9999 and (d <= 1).mean() >= 0.999
+        assert s0.rays_primary == s1.rays_primary
+        assert (rgb2 == rgb0).all() and (hits2 == hits0).all()
