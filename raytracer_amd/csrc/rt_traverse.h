@@ -666,6 +666,22 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             return false;
         };
 
+        // RT_FLAG_NEAR_FIRST only: leaves are no longer met in the reference's order, so a triangle that ties with
+        // the best so far (equal t) is let through the test (bound one ulp up) and wins if it comes earlier in the
+        // reference's order — triangle records are stored in that order.  Helpers record every tie; the owner
+        // decides at the replay.  With this the mode returns the triangle the reference returns whenever the
+        // reference's box culls agree with its triangle tests.
+        auto tbound = [&]() -> float {
+            if constexpr (NEAR) {
+                if (!RT_ISANY && (helper || mesh_found) && tmax < RT_INF && tmax > 0.0f) return __uint_as_float(__float_as_uint(tmax) + 1u);
+            }
+            return tmax;
+        };
+        auto wins = [&](float t, uint32_t ti) -> bool {
+            if constexpr (NEAR) return RT_ISANY || helper || !mesh_found || t < tmax || ti < mesh_tri;
+            return true;
+        };
+
         // ---- triangle phase: the postponed leaves, in visiting order (raytracer.cpp:781-798)
         bool fin = false;        // this lane's ray / subtree is finished by an any-hit
         for (uint32_t qi = 0; qi < qn && !fin; qi++) {
@@ -694,8 +710,8 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
 #pragma unroll
                 for (uint32_t u = 0; u < RT_TRI_UNROLL; u++) {
                     float t, bb, gg;
-                    if (u < m && !fin && tri_test(ar, ta[u].x, ta[u].y, ta[u].z, ta[u].w, tb[u].x, tb[u].y, tb[u].z, tb[u].w, tc[u], tmax, t, bb, gg)) {
-                        if (accept(ti + u, t, bb, gg, te)) fin = true;
+                    if (u < m && !fin && tri_test(ar, ta[u].x, ta[u].y, ta[u].z, ta[u].w, tb[u].x, tb[u].y, tb[u].z, tb[u].w, tc[u], tbound(), t, bb, gg)) {
+                        if (wins(t, ti + u) && accept(ti + u, t, bb, gg, te)) fin = true;
                     }
                 }
                 n -= m;
@@ -727,8 +743,8 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                         const f4u ta = *reinterpret_cast<const f4u*>(tp), tb = *reinterpret_cast<const f4u*>(tp + 4);
                         const float tc = tp[8];
                         float t, bb, gg;
-                        if (tri_test(ar, ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w, tc, tmax, t, bb, gg)) {
-                            if (accept(ti, t, bb, gg, cur_t)) { fin = true; break; }
+                        if (tri_test(ar, ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w, tc, tbound(), t, bb, gg)) {
+                            if (wins(t, ti) && accept(ti, t, bb, gg, cur_t)) { fin = true; break; }
                         }
                     }
                 }
@@ -742,7 +758,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 br.ox = lane_bcast(ar.ox, src); br.oy = lane_bcast(ar.oy, src); br.oz = lane_bcast(ar.oz, src);
                 br.dx = lane_bcast(ar.dx, src); br.dy = lane_bcast(ar.dy, src); br.dz = lane_bcast(ar.dz, src);
                 br.ix = br.iy = br.iz = 0.f;         // not used by tri_test
-                const float bound = lane_bcast(tmax, src);
+                const float bound = lane_bcast(tbound(), src);
                 const uint32_t first = lane_bcast(big_first, src), count = lane_bcast(big_n, src);
                 float best_t = bound, best_b = 0.f, best_g = 0.f;
                 uint32_t best_i = 0xFFFFFFFFu;
@@ -766,7 +782,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     const int win = __ffsll((long long)__ballot(best_i == red_i)) - 1;
                     const float wb = lane_bcast(best_b, win), wg = lane_bcast(best_g, win);
                     if ((int)lane == src) {
-                        if (accept(red_i, red_t, wb, wg, cur_t)) fin = true;
+                        if (wins(red_t, red_i) && accept(red_i, red_t, wb, wg, cur_t)) fin = true;
                     }
                 }
             }
@@ -831,7 +847,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                             last = best.x;
                             const float ct = __uint_as_float(best.y), cte = __uint_as_float(best.z);
                             if ((tmax < cte) || (cte == 0.0f && tmax <= 0.0f)) continue;     // leaf culled by now
-                            if (ct < tmax) { tmax = ct; mesh_found = true; mesh_tri = best.x; from_cand = true; }
+                            if (ct < tmax || (NEAR && !RT_ISANY && mesh_found && ct == tmax && best.x < mesh_tri)) { tmax = ct; mesh_found = true; mesh_tri = best.x; from_cand = true; }
                         }
                         if (from_cand) {
                             // beta / gamma of the winner: the same test on the same operands gives the same bits
