@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""Other BASELINE.json configurations as performance cases (not bench lines): one line each."""
+"""Other BASELINE.json configurations as performance cases (not bench lines): one line each.
+   RT_NEAR=1 in the environment selects the non-parity visiting order (RT_FLAG_NEAR_FIRST)."""
 import os, sys, time
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
-from raytracer_amd import DeviceScene, Stats, RT_OPT_FLAGS, RT_FLAG_TIMING, scenes
+from raytracer_amd import DeviceScene, Stats, RT_OPT_FLAGS, RT_FLAG_TIMING, RT_FLAG_NEAR_FIRST, scenes
+NEAR = RT_FLAG_NEAR_FIRST if os.environ.get("RT_NEAR") == "1" else 0
 cases = [
     ("mesh1m 1920x1080 1spp depth0 (configs[1])", lambda: scenes.mesh_scene(709, 1920, 1080)),
     ("mesh1m 3840x2160 1spp depth0", lambda: scenes.mesh_scene(709, 3840, 2160)),
@@ -18,7 +20,7 @@ for name, mk in cases:
     hs = mk().build()
     cam = hs.camera(0)
     ds = DeviceScene(hs, 0)
-    ds.set_option(RT_OPT_FLAGS, RT_FLAG_TIMING)
+    ds.set_option(RT_OPT_FLAGS, RT_FLAG_TIMING | NEAR)
     import torch
     fb = torch.zeros((cam.image_height, cam.image_width, 3), dtype=torch.uint8, device="cuda")
     best = None
