@@ -263,6 +263,16 @@ int rt_device_count(void);
  * at raytracer.cpp:30.  Synchronous. */
 int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out);
 
+/* rt_upload_scene with flags.  RT_UPLOAD_REBUILD_MESH_BVH: NON-PARITY mode — the mesh BVHs of the scene
+ * (mesh_nodes / mesh_prim_face, built by SubdivideMesh's midpoint splits, raytracer.cpp:296-339, which leaves deep
+ * trees and, where centroids coincide, leaves of thousands of triangles: blog/hw2/episode2.md:240-248) are ignored
+ * and rebuilt by the library with a binned surface-area heuristic over the same faces; the scene is then always
+ * traced as with RT_FLAG_NEAR_FIRST, ties going to the triangle that comes first in the CALLER's leaf order.
+ * Frames equal the reference's wherever its box culls agree with its triangle tests; hit ids and
+ * colours are tested to the north_star's tolerance, not to byte-exactness.  flags == 0 is rt_upload_scene. */
+enum { RT_UPLOAD_REBUILD_MESH_BVH = 1u };
+int rt_upload_scene_ex(int device, const rt_scene_desc* scene, uint32_t flags, rt_scene** out);
+
 /* Next frame of an animation whose meshes do not change: re-derive everything
  * in `scene` except the mesh level (mesh_bvhs, mesh_nodes, mesh_prim_face,
  * faces, vertex_data must be what rt_upload_scene saw) and keep the mesh BVHs,

@@ -102,6 +102,7 @@ struct DScene {
     const DTri*       tris;
     const DTriShade*  tri_shade;
     const float4*     vnormals;      // vertex normal per vertex_data entry (w unused)
+    const uint32_t*   tri_rank;      // NULL, or per triangle record its position in the reference's leaf order (rebuilt BVHs, rt_rebuild.h)
     const DObject*    objects;
     const DTopPrim*   top_prims;
     const DPlane*     planes;

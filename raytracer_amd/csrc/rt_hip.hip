@@ -19,6 +19,7 @@
 #include "rt_kernels.h"
 #include "rt_ordered.h"
 #include "rt_upload.h"
+#include "rt_rebuild.h"
 
 namespace {
 
@@ -92,6 +93,8 @@ struct rt_scene {
     // device scene
     DevBuf b_big, b_nodes, b_tris, b_tri_shade, b_vnormals, b_objects, b_top_prims, b_planes, b_materials, b_lights, b_area_lights;
     DScene ds{};
+    DevBuf b_tri_rank;                // rebuilt mesh BVHs only (rt_rebuild.h)
+    bool rebuilt = false;             // uploaded with RT_UPLOAD_REBUILD_MESH_BVH: always traced nearest-first
     bool has_reflective = false;      // any material with type != None
     bool needs_sequential_rng = false;   // area lights or rough reflective materials (RNG drawn while shading)
     uint32_t n_point_lights = 0, n_area_lights = 0;
@@ -667,9 +670,35 @@ int build_top_level(rt_scene* sc, const rt_scene_desc* s) {
     return RT_OK;
 }
 
-int build_device_scene(rt_scene* sc, const rt_scene_desc* s) {
-    int rc = build_mesh_level(sc, s);
-    return rc ? rc : build_top_level(sc, s);
+int build_device_scene(rt_scene* sc, const rt_scene_desc* s, uint32_t upload_flags) {
+    int rc;
+    if (upload_flags & RT_UPLOAD_REBUILD_MESH_BVH) {
+        // non-parity mode: the mesh level is laid out from binned-SAH trees over the same faces (rt_rebuild.h);
+        // everything downstream is the code of the parity path
+        PhaseClock pc;
+        uint32_t max_leaf = 4;
+        if (const char* e = getenv("RT_REBUILD_MAX_LEAF")) max_leaf = (uint32_t)std::max(2, std::min(30, atoi(e)));
+        rt_rebuild::MeshLevel R;
+        rt_rebuild::rebuild(s, max_leaf, R);
+        pc.lap("SAH rebuild (host)");
+        rt_scene_desc s2 = *s;
+        s2.mesh_nodes = R.nodes.data(); s2.n_mesh_nodes = (uint32_t)R.nodes.size();
+        s2.mesh_bvhs = R.bvhs.data();
+        s2.mesh_prim_face = R.prim_face.data();
+        for (uint32_t b = 0; b < s2.n_mesh_bvhs; b++)
+            if ((rc = validate_bvh(s2.mesh_nodes + s2.mesh_bvhs[b].node_offset, s2.mesh_bvhs[b].node_count, s2.mesh_bvhs[b].prim_count, "rebuilt mesh BVH"))) return rc;
+        if ((rc = build_mesh_level(sc, &s2))) return rc;
+        // rt_update_scene compares the caller's arrays with what the caller uploaded
+        sc->mesh.n_mesh_nodes = s->n_mesh_nodes;
+        sc->mesh.hash = mesh_hash(s);
+        if ((rc = upload_vec(sc->b_tri_rank, R.rank))) return rc;
+        sc->ds.tri_rank = R.rank.empty() ? nullptr : (const uint32_t*)sc->b_tri_rank.p;
+        sc->rebuilt = true;
+    } else {
+        if ((rc = build_mesh_level(sc, s))) return rc;
+        sc->ds.tri_rank = nullptr;
+    }
+    return build_top_level(sc, s);
 }
 
 // The record pool grows to what a render needs, up to RT_OPT_POOL_RECORDS (27 GB at its default of 256 M records:
@@ -757,7 +786,7 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
 
     const bool want_sync = stats != nullptr || (sc->opt_flags & RT_FLAG_TIMING) || D > 0 || sc->needs_sequential_rng;
     Timer tm{sc, st, (sc->opt_flags & RT_FLAG_TIMING) != 0};
-    const bool near = (sc->opt_flags & RT_FLAG_NEAR_FIRST) != 0;   // non-parity visiting order (rt.h)
+    const bool near = (sc->opt_flags & RT_FLAG_NEAR_FIRST) != 0 || sc->rebuilt;   // non-parity visiting order (rt.h)
     HIPCHK(hipMemsetAsync(ctl, 0, sizeof(Control), st));
 
     hipEvent_t ev_total_a = nullptr, ev_total_b = nullptr;
@@ -1007,8 +1036,11 @@ int rt_device_count(void) {
     return n;
 }
 
-int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out) {
+int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out) { return rt_upload_scene_ex(device, scene, 0u, out); }
+
+int rt_upload_scene_ex(int device, const rt_scene_desc* scene, uint32_t upload_flags, rt_scene** out) {
     if (!out) return fail(RT_ERR_INVALID, "out is NULL");
+    if (upload_flags & ~(uint32_t)RT_UPLOAD_REBUILD_MESH_BVH) return fail(RT_ERR_INVALID, "unknown upload flag");
     *out = nullptr;
     int n = rt_device_count();
     if (n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
@@ -1024,7 +1056,7 @@ int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) sc->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess) { delete sc; return fail(RT_ERR_HIP, "hipStreamCreate failed"); }
     if (hipHostMalloc((void**)&sc->h_ctl, sizeof(Control)) != hipSuccess) { rt_free_scene(sc); return fail(RT_ERR_HIP, "hipHostMalloc failed"); }
-    rc = build_device_scene(sc, scene);
+    rc = build_device_scene(sc, scene, upload_flags);
     if (rc) { rt_free_scene(sc); return rc; }
     // persistent grids: as many workgroups as are resident at once (RT_TRACE_BLOCKS_PER_CU caps it, for occupancy experiments)
     int per_cu = 0, cap = 8;
@@ -1144,7 +1176,7 @@ void rt_free_scene(rt_scene* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (DevBuf* b : {&s->b_big, &s->b_nodes, &s->b_tris, &s->b_tri_shade, &s->b_vnormals, &s->b_objects, &s->b_top_prims, &s->b_planes,
                       &s->b_materials, &s->b_lights, &s->b_ray0, &s->b_ray1, &s->b_hit0, &s->b_hit1, &s->b_nrm, &s->b_link,
-                      &s->b_color, &s->b_shadow_rec, &s->b_shadow_lit, &s->b_ctl, &s->b_spill, &s->b_cand, &s->b_mt, &s->b_frames, &s->b_area_lights, &s->b_fb, &s->b_hits})
+                      &s->b_color, &s->b_shadow_rec, &s->b_shadow_lit, &s->b_ctl, &s->b_spill, &s->b_cand, &s->b_mt, &s->b_frames, &s->b_area_lights, &s->b_fb, &s->b_hits, &s->b_tri_rank})
         b->release();
     for (auto& e : s->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }

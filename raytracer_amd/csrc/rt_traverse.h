@@ -677,8 +677,10 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             }
             return tmax;
         };
+        // (a rebuilt tree stores its triangles in its own leaf order: the reference's is then a side array)
+        auto earlier = [&](uint32_t a, uint32_t b) -> bool { return S.tri_rank ? S.tri_rank[a] < S.tri_rank[b] : a < b; };
         auto wins = [&](float t, uint32_t ti) -> bool {
-            if constexpr (NEAR) return RT_ISANY || helper || !mesh_found || t < tmax || ti < mesh_tri;
+            if constexpr (NEAR) return RT_ISANY || helper || !mesh_found || t < tmax || earlier(ti, mesh_tri);
             return true;
         };
 
@@ -847,7 +849,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                             last = best.x;
                             const float ct = __uint_as_float(best.y), cte = __uint_as_float(best.z);
                             if ((tmax < cte) || (cte == 0.0f && tmax <= 0.0f)) continue;     // leaf culled by now
-                            if (ct < tmax || (NEAR && !RT_ISANY && mesh_found && ct == tmax && best.x < mesh_tri)) { tmax = ct; mesh_found = true; mesh_tri = best.x; from_cand = true; }
+                            if (ct < tmax || (NEAR && !RT_ISANY && mesh_found && ct == tmax && (S.tri_rank ? S.tri_rank[best.x] < S.tri_rank[mesh_tri] : best.x < mesh_tri))) { tmax = ct; mesh_found = true; mesh_tri = best.x; from_cand = true; }
                         }
                         if (from_cand) {
                             // beta / gamma of the winner: the same test on the same operands gives the same bits

@@ -14,6 +14,7 @@ RT_MAT_NONE, RT_MAT_MIRROR, RT_MAT_CONDUCTOR, RT_MAT_DIELECTRIC = 0, 1, 2, 3
 RT_FLAG_TIMING = 1
 RT_FLAG_SEPARATE_LAUNCHES = 2
 RT_FLAG_NEAR_FIRST = 4        # non-parity visiting order, see include/rt.h
+RT_UPLOAD_REBUILD_MESH_BVH = 1
 RT_UPDATE_VERIFY_MESHES = 1
 RT_OPT_FLAGS, RT_OPT_POOL_RECORDS, RT_OPT_CHUNK_SAMPLES = 1, 2, 3
 
@@ -295,6 +296,7 @@ def hip_lib():
         L = _load(os.environ.get("RT_HIP_SO", "librt_hip.so"))   # RT_HIP_SO: experiment builds (make variant)
         L.rt_device_count.restype = C.c_int
         L.rt_upload_scene.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.rt_upload_scene_ex.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
         L.rt_scene_set_option.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
         L.rt_update_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.rt_render_tile.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_int, C.c_int,
@@ -320,10 +322,15 @@ def _check(rc):
 class DeviceScene:
     """A scene resident on one GPU (rt_scene*)."""
 
-    def __init__(self, host_scene, device=0):
+    def __init__(self, host_scene, device=0, rebuild_mesh_bvh=False):
+        """rt_upload_scene; rebuild_mesh_bvh=True is rt_upload_scene_ex(RT_UPLOAD_REBUILD_MESH_BVH), the non-parity
+        mode in which the library builds its own SAH trees over the meshes (include/rt.h)."""
         L = hip_lib()
         h = C.c_void_p()
-        _check(L.rt_upload_scene(device, host_scene.desc_ptr, C.byref(h)))
+        if rebuild_mesh_bvh:
+            _check(L.rt_upload_scene_ex(device, host_scene.desc_ptr, RT_UPLOAD_REBUILD_MESH_BVH, C.byref(h)))
+        else:
+            _check(L.rt_upload_scene(device, host_scene.desc_ptr, C.byref(h)))
         self._h = h
         self.device = device
 

@@ -19,7 +19,11 @@ for spec in sys.argv[1:]:
     cam = hs.camera(0)
     ds = rt.DeviceScene(hs, 0)
     rgb0, h0 = ds.render(cam, want_hits=True)
-    ds.set_option(rt.RT_OPT_FLAGS, rt.RT_FLAG_NEAR_FIRST)
+    if os.environ.get("RT_REBUILD") == "1":      # compare the exact mode with the library's own SAH trees instead
+        ds.close()
+        ds = rt.DeviceScene(hs, 0, rebuild_mesh_bvh=True)
+    else:
+        ds.set_option(rt.RT_OPT_FLAGS, rt.RT_FLAG_NEAR_FIRST)
     rgb1, h1 = ds.render(cam, want_hits=True)
     ds.close()
     a0, a1 = h0.reshape(-1, 2), h1.reshape(-1, 2)

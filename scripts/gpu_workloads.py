@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Other BASELINE.json configurations as performance cases (not bench lines): one line each.
-   RT_NEAR=1 in the environment selects the non-parity visiting order (RT_FLAG_NEAR_FIRST)."""
+   RT_NEAR=1 in the environment selects the non-parity visiting order (RT_FLAG_NEAR_FIRST), RT_REBUILD=1 the
+   library's own SAH trees (rt_upload_scene_ex, RT_UPLOAD_REBUILD_MESH_BVH)."""
 import os, sys, time
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 from raytracer_amd import DeviceScene, Stats, RT_OPT_FLAGS, RT_FLAG_TIMING, RT_FLAG_NEAR_FIRST, scenes
@@ -19,7 +20,7 @@ for name, mk in cases:
         continue
     hs = mk().build()
     cam = hs.camera(0)
-    ds = DeviceScene(hs, 0)
+    ds = DeviceScene(hs, 0, rebuild_mesh_bvh=os.environ.get("RT_REBUILD") == "1")
     ds.set_option(RT_OPT_FLAGS, RT_FLAG_TIMING | NEAR)
     import torch
     fb = torch.zeros((cam.image_height, cam.image_width, 3), dtype=torch.uint8, device="cuda")

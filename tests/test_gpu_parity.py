@@ -354,3 +354,64 @@ def test_near_first_mode_vs_exact_mode_on_synthetic_meshes(rt):
         assert same.mean() >= 0.9999 and (d <= 1).mean() >= 0.999
         assert s0.rays_primary == s1.rays_primary
         assert (rgb2 == rgb0).all() and (hits2 == hits0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GOLD)
+def test_rebuilt_mesh_bvh_mode_meets_the_north_star_tolerance_on_reference_scenes(rt, name):
+    """rt_upload_scene_ex(RT_UPLOAD_REBUILD_MESH_BVH), the second NON-PARITY mode: the library ignores
+    the reference's midpoint-split mesh BVHs (raytracer.cpp:296-339) and builds SAH trees over the same faces
+    (rt_rebuild.h); ties go by the caller's leaf order.  Same bar as the near-first mode, against the reference's
+    own renders."""
+    hs = util.golden_scene(name)
+    cam = hs.camera(0)
+    ds = rt.DeviceScene(hs, 0, rebuild_mesh_bvh=True)
+    tile = util.golden_tile(name) or (0, 0, cam.image_width, cam.image_height)
+    rgb, hits = ds.render(cam, *tile, want_hits=True)
+    ds.close()
+    st = util.image_stats(rgb, util.golden_image(name))
+    ok = util.hit_ids_match(hits, util.golden_hits(name))
+    print(f"rebuilt {name}: hit ids {ok.mean():.6f} exact {st['exact']:.6f} within1 {st['within1']:.6f}")
+    assert ok.mean() >= 0.9999, f"hit-id agreement {ok.mean()}"
+    assert st["within1"] >= 0.999, st
+
+
+@pytest.mark.gpu
+def test_rebuilt_mesh_bvh_mode_vs_exact_mode_and_scene_update(rt):
+    """The rebuilt mode against the exact mode of the same library on the bench's scene family, and
+    rt_update_scene on a rebuilt scene: the caller passes its own (reference) mesh arrays again, the library keeps
+    its own trees."""
+    for spec in (rt.scenes.mesh_scene(grid=256, width=960, height=540),
+                 rt.scenes.instanced_scene(grid=128, width=640, height=360),
+                 rt.scenes.glossy_area_scene(grid=48, width=320, height=200, num_samples=4)):
+        hs = spec.build()
+        cam = hs.camera(0)
+        ds = rt.DeviceScene(hs, 0)
+        s0, s1 = rt.Stats(), rt.Stats()
+        rgb0, hits0 = ds.render(cam, want_hits=True, stats=s0)
+        ds.close()
+        ds = rt.DeviceScene(hs, 0, rebuild_mesh_bvh=True)
+        rgb1, hits1 = ds.render(cam, want_hits=True, stats=s1)
+        ds.update(hs, verify_meshes=True)
+        rgb2, hits2 = ds.render(cam, want_hits=True)
+        ds.close()
+        same = (hits0.reshape(-1, 2) == hits1.reshape(-1, 2)).all(axis=1)
+        d = np.abs(rgb0.astype(np.int16) - rgb1.astype(np.int16)).max(axis=-1)
+        print(f"rebuilt {spec.name}: hit ids {same.mean():.6f} exact {(d == 0).mean():.6f} within1 {(d <= 1).mean():.6f}")
+        assert same.mean() >= 0.9999 and (d <= 1).mean() >= 0.999
+        assert s0.rays_primary == s1.rays_primary
+        assert (rgb2 == rgb1).all() and (hits2 == hits1).all()
+    # frames of an animation over a rebuilt scene equal the exact mode's
+    frames = [rt.scenes.instanced_scene(grid=64, width=320, height=180, frame=f).build() for f in range(3)]
+    ds = rt.DeviceScene(frames[0], 0, rebuild_mesh_bvh=True)
+    ex = rt.DeviceScene(frames[0], 0)
+    for f, hs in enumerate(frames):
+        if f:
+            ds.update(hs)
+            ex.update(hs)
+        a, _ = ds.render(hs.camera(0))
+        b, _ = ex.render(hs.camera(0))
+        d = np.abs(a.astype(np.int16) - b.astype(np.int16)).max(axis=-1)
+        assert (d <= 1).mean() >= 0.999, f
+    ds.close()
+    ex.close()
