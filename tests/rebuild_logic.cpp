@@ -126,6 +126,15 @@ int main() {
             add_tri(three, p0, p1, p2); add_tri(three, p0, p1, p3); add_tri(three, p0, p2, p3);
             check_scene("soup + tiny + empty", {soup, one, none, three}, max_leaf, rng);
         }
+        if (max_leaf == 4) {   // large enough for the parallel binning of the upper levels (>= 65536 triangles)
+            Mesh big;
+            for (int i = 0; i < 150000; i++) {
+                float c[3] = {U(rng) * 30, U(rng) * 3, U(rng) * 10}, a[3], b[3], d[3];
+                for (int k = 0; k < 3; k++) { a[k] = c[k] + U(rng) * .1f; b[k] = c[k] + U(rng) * .1f; d[k] = c[k] + U(rng) * .1f; }
+                add_tri(big, a, b, d);
+            }
+            check_scene("large soup", {big}, max_leaf, rng);
+        }
         {   // regular grid (the bench mesh's kind), long thin extent
             Mesh grid;
             const int W = 300, H = 40;

@@ -10,8 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_rebuilt_trees_are_valid_reference_format(tmp_path):
     exe = str(tmp_path / "rebuild_logic")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-o", exe,
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"), "-o", exe,
                     os.path.join(ROOT, "tests", "rebuild_logic.cpp")], check=True, cwd=ROOT)
-    out = subprocess.run([exe], capture_output=True, text=True)
-    assert out.returncode == 0, out.stdout[-3000:]
-    assert "total: 0 failures" in out.stdout, out.stdout[-3000:]
+    for threads in ("8", "1"):      # subtrees grown side by side and spliced / the serial build
+        out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, RT_REBUILD_THREADS=threads))
+        assert out.returncode == 0, out.stdout[-3000:]
+        assert "total: 0 failures" in out.stdout, out.stdout[-3000:]
