@@ -415,3 +415,73 @@ def test_rebuilt_mesh_bvh_mode_vs_exact_mode_and_scene_update(rt):
         assert (d <= 1).mean() >= 0.999, f
     ds.close()
     ex.close()
+
+
+@pytest.mark.gpu
+def test_unsplittable_big_leaves_vs_oracle_in_all_modes(rt):
+    """The dragon_new pathology (blog/hw2/episode2.md:240-248): SubdivideMesh gives up when every centroid falls on
+    one side of the midpoint (raytracer.cpp:317), leaving a leaf of hundreds of triangles.  Two decks of stacked
+    right triangles (centroid at a third of the extent, midpoint at half: never split) of 300 and 100 triangles
+    under two interior nodes, one deck a mirror, lit by a point light: closest hits, any-hits and secondary rays
+    all run through big leaves — the whole-wave test, the lane-alone test, the side table of leaf sizes.  Exact
+    mode against the oracle byte for byte; the two non-parity modes against the exact frame."""
+    from oracle import binding as ob
+    from raytracer_amd import scenes
+
+    def deck(n, x0, z0, dz, shrink):
+        v, f = [], []
+        for k in range(n):
+            s, z = 1.0 - shrink * k, z0 + dz * k
+            v += [(x0, -1.0, z), (x0 + 4.0 * s, -1.0, z), (x0, -1.0 + 2.0 * s, z)]
+            f.append((3 * k, 3 * k + 1, 3 * k + 2))
+        return v, f
+
+    v1, f1 = deck(300, -5.0, -3.0, 0.002, 0.002)
+    v2, f2 = deck(100, 1.0, -2.5, -0.004, 0.005)
+    verts = np.array(v1 + v2 + [(-6, -1.2, 2), (6, -1.2, 2), (6, -1.2, -6), (-6, -1.2, -6)], np.float32)
+    nb = len(v1) + len(v2)
+    faces = np.array(f1 + [(a + len(v1), b + len(v1), c + len(v1)) for a, b, c in f2] + [(nb, nb + 1, nb + 2), (nb, nb + 2, nb + 3)], np.int32)
+    s = scenes.SynthScene("big_leaves")
+    s.background = (20, 30, 40)
+    s.max_depth = 3
+    s.materials = [dict(ambient=(1, 1, 1), diffuse=(0.7, 0.6, 0.5), specular=(0.4, 0.4, 0.4), phong=20.0),
+                   dict(type=rt.ffi.RT_MAT_MIRROR, ambient=(0.1, 0.1, 0.1), diffuse=(0.2, 0.2, 0.2), specular=(1, 1, 1), mirror=(0.8, 0.8, 0.8), phong=50.0)]
+    s.point_lights = [((1.0, 6.0, 4.0), (60000, 60000, 60000))]
+    s.meshes = [dict(verts=verts, faces=faces, material=1),
+                dict(verts=np.array(v2, np.float32) + np.float32([0.0, 2.2, 0.3]), faces=np.array(f2, np.int32), material=2)]
+    s.camera = dict(position=(0.0, 1.0, 7.0), gaze_point=(0, 0, -2), up=(0, 1, 0), fovy=50.0, near=1.0, width=480, height=270, num_samples=1)
+    hs = s.build()
+    cam = hs.camera(0)
+    # the premise: the reference's builder left big leaves
+    import ctypes as C
+
+    class Node(C.Structure):      # rt_bvh_node
+        _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("left_or_first", C.c_int32), ("prim_count", C.c_int32)]
+
+    class DescHead(C.Structure):  # the first fields of rt_scene_desc (include/rt.h)
+        _fields_ = [("background", C.c_float * 3), ("ambient", C.c_float * 3), ("eps", C.c_float), ("max_depth", C.c_int32),
+                    ("top_nodes", C.c_void_p), ("n_top_nodes", C.c_uint32), ("top_prim_idx", C.c_void_p), ("n_top_prims", C.c_uint32),
+                    ("top_prims", C.c_void_p), ("mesh_bvhs", C.c_void_p), ("n_mesh_bvhs", C.c_uint32),
+                    ("mesh_nodes", C.POINTER(Node)), ("n_mesh_nodes", C.c_uint32)]
+
+    d = DescHead.from_address(hs.desc_ptr)
+    counts = sorted(d.mesh_nodes[i].prim_count for i in range(d.n_mesh_nodes))
+    assert d.n_mesh_bvhs == 2 and counts[-1] >= 300 and counts[-2] >= 100 and counts[-3] >= 100, counts[-4:]
+    o_rgb, o_hits, ctr = ob.render(hs, cam, want_hits=True)
+    ds = rt.DeviceScene(hs, 0)
+    st = rt.Stats()
+    rgb, hits = ds.render(cam, want_hits=True, stats=st)
+    assert (hits == o_hits).all() and (rgb == o_rgb).all(), int((rgb != o_rgb).any(-1).sum())
+    assert st.rays_primary == ctr.rays_primary and st.rays_secondary == ctr.rays_secondary and st.rays_shadow == ctr.s_rays
+    assert (hits.reshape(-1, 2)[:, 0] != 0xFFFFFFFF).mean() > 0.25         # the decks fill a good part of the frame
+    ds.set_option(rt.RT_OPT_FLAGS, rt.RT_FLAG_NEAR_FIRST)
+    rgb1, hits1 = ds.render(cam, want_hits=True)
+    ds.close()
+    ds = rt.DeviceScene(hs, 0, rebuild_mesh_bvh=True)
+    rgb2, hits2 = ds.render(cam, want_hits=True)
+    ds.close()
+    for name, r, h in (("near-first", rgb1, hits1), ("rebuilt", rgb2, hits2)):
+        same = (h.reshape(-1, 2) == hits.reshape(-1, 2)).all(axis=1)
+        dd = np.abs(r.astype(np.int16) - rgb.astype(np.int16)).max(axis=-1)
+        print(f"big leaves, {name}: hit ids {same.mean():.6f} exact {(dd == 0).mean():.6f}")
+        assert same.mean() >= 0.9999 and (dd <= 1).mean() >= 0.999
