@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <chrono>
+#include <new>
 #include <vector>
 
 #include "rt.h"
@@ -1025,6 +1026,21 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
 
 }  // namespace
 
+// rt.h: nothing throws across the boundary.  The host side allocates (std::vector, std::thread); a failure there
+// becomes a status like any other.
+template <class F>
+static int guarded(F f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail(RT_ERR_OOM, "host allocation failed");
+    } catch (const std::exception& e) {
+        return fail(RT_ERR_INVALID, "internal error: %s", e.what());
+    } catch (...) {
+        return fail(RT_ERR_INVALID, "internal error");
+    }
+}
+
 extern "C" {
 
 const char* rt_last_error(void) { return g_err.c_str(); }
@@ -1046,17 +1062,18 @@ int rt_upload_scene_ex(int device, const rt_scene_desc* scene, uint32_t upload_f
     if (n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= n) return fail(RT_ERR_NO_DEVICE, "device %d out of range [0,%d)", device, n);
     PhaseClock pc;
-    int rc = validate_scene(scene);
+    int rc = guarded([&] { return validate_scene(scene); });
     if (rc) return rc;
     pc.lap("validate_scene");
     HIPCHK(hipSetDevice(device));
-    rt_scene* sc = new rt_scene();
+    rt_scene* sc = new (std::nothrow) rt_scene();
+    if (!sc) return fail(RT_ERR_OOM, "host allocation failed");
     sc->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) sc->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess) { delete sc; return fail(RT_ERR_HIP, "hipStreamCreate failed"); }
     if (hipHostMalloc((void**)&sc->h_ctl, sizeof(Control)) != hipSuccess) { rt_free_scene(sc); return fail(RT_ERR_HIP, "hipHostMalloc failed"); }
-    rc = build_device_scene(sc, scene, upload_flags);
+    rc = guarded([&] { return build_device_scene(sc, scene, upload_flags); });
     if (rc) { rt_free_scene(sc); return rc; }
     // persistent grids: as many workgroups as are resident at once (RT_TRACE_BLOCKS_PER_CU caps it, for occupancy experiments)
     int per_cu = 0, cap = 8;
@@ -1073,7 +1090,7 @@ int rt_upload_scene_ex(int device, const rt_scene_desc* scene, uint32_t upload_f
 
 int rt_update_scene(rt_scene* sc, const rt_scene_desc* scene, uint32_t flags) {
     if (!sc) return fail(RT_ERR_INVALID, "scene is NULL");
-    int rc = validate_scene(scene, false);
+    int rc = guarded([&] { return validate_scene(scene, false); });
     if (rc) return rc;
     const rt_scene::MeshLevel& M = sc->mesh;
     if (scene->n_mesh_bvhs != M.n_mesh_bvhs || scene->n_mesh_nodes != M.n_mesh_nodes || scene->n_mesh_prims != M.n_mesh_prims ||
@@ -1083,7 +1100,7 @@ int rt_update_scene(rt_scene* sc, const rt_scene_desc* scene, uint32_t flags) {
         return fail(RT_ERR_INVALID, "rt_update_scene: the mesh arrays differ from the uploaded scene's; upload the scene instead");
     HIPCHK(hipSetDevice(sc->device));
     HIPCHK(hipStreamSynchronize(sc->stream));      // no render of this scene may be in flight (the caller's stream: caller's duty)
-    return build_top_level(sc, scene);
+    return guarded([&] { return build_top_level(sc, scene); });
 }
 
 int rt_scene_set_option(rt_scene* s, int option, uint64_t value) {
@@ -1106,7 +1123,7 @@ int rt_render_tile_device(rt_scene* s, const rt_camera_desc* cam, int x0, int y0
                           size_t rgb_row_stride_bytes, void* d_hit_id_out, rt_stats* stats, void* hip_stream) {
     if (!s) return fail(RT_ERR_INVALID, "scene is NULL");
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
-    return render_impl(s, cam, x0, y0, tile_w, tile_h, 1, 0, (uint8_t*)d_rgb_out, rgb_row_stride_bytes, (uint32_t*)d_hit_id_out, stats, st);
+    return guarded([&] { return render_impl(s, cam, x0, y0, tile_w, tile_h, 1, 0, (uint8_t*)d_rgb_out, rgb_row_stride_bytes, (uint32_t*)d_hit_id_out, stats, st); });
 }
 
 int rt_render_tile_rows_device(rt_scene* s, const rt_camera_desc* cam, int x0, int y0, int tile_w, int tile_h, int row_parts,
@@ -1114,8 +1131,10 @@ int rt_render_tile_rows_device(rt_scene* s, const rt_camera_desc* cam, int x0, i
                                void* hip_stream) {
     if (!s) return fail(RT_ERR_INVALID, "scene is NULL");
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
-    return render_impl(s, cam, x0, y0, tile_w, tile_h, row_parts, row_part, (uint8_t*)d_rgb_out, rgb_row_stride_bytes,
-                       (uint32_t*)d_hit_id_out, stats, st);
+    return guarded([&] {
+        return render_impl(s, cam, x0, y0, tile_w, tile_h, row_parts, row_part, (uint8_t*)d_rgb_out, rgb_row_stride_bytes,
+                           (uint32_t*)d_hit_id_out, stats, st);
+    });
 }
 
 int rt_render_tile(rt_scene* s, const rt_camera_desc* cam, int x0, int y0, int tile_w, int tile_h, uint8_t* rgb_out,
@@ -1127,8 +1146,10 @@ int rt_render_tile(rt_scene* s, const rt_camera_desc* cam, int x0, int y0, int t
     int rc = s->b_fb.ensure(fb_bytes);
     if (rc) return rc;
     if (hit_id_out && (rc = s->b_hits.ensure(hit_bytes))) return rc;
-    rc = render_impl(s, cam, x0, y0, tile_w, tile_h, 1, 0, (uint8_t*)s->b_fb.p, (size_t)tile_w * 3, hit_id_out ? (uint32_t*)s->b_hits.p : nullptr,
-                     stats, s->stream);
+    rc = guarded([&] {
+        return render_impl(s, cam, x0, y0, tile_w, tile_h, 1, 0, (uint8_t*)s->b_fb.p, (size_t)tile_w * 3, hit_id_out ? (uint32_t*)s->b_hits.p : nullptr,
+                           stats, s->stream);
+    });
     if (rc) return rc;
     // device -> pinned staging (one contiguous copy at PCIe rate) -> the caller's rows; a 2-D copy straight into
     // pageable memory took 7.5 ms for a 1920x1080 frame, this takes well under 1 ms

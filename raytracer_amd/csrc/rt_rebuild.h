@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <vector>
 #include "rt.h"
@@ -49,14 +50,24 @@ inline unsigned host_threads() {
     return std::max(1u, std::min(n, 16u));
 }
 
-// fn(t, T) on T threads (T == 1: inline)
+// fn(t, T) for every share t of T, on T threads (T == 1: inline).  A share whose thread cannot be started runs on
+// the calling thread; an exception in any share is rethrown here as std::bad_alloc after all threads have joined
+// (nothing may unwind out of a std::thread).
 template <class F>
 inline void on_threads(unsigned T, F fn) {
     if (T <= 1) { fn(0u, 1u); return; }
+    std::atomic<bool> failed{false};
+    auto run = [&](unsigned t) { try { fn(t, T); } catch (...) { failed = true; } };
     std::vector<std::thread> th;
-    for (unsigned t = 1; t < T; t++) th.emplace_back([=]() { fn(t, T); });
-    fn(0u, T);
+    unsigned started = 1;
+    try {
+        th.reserve(T - 1);
+        for (; started < T; started++) th.emplace_back(run, started);
+    } catch (...) {}
+    run(0u);
+    for (unsigned t = started; t < T; t++) run(t);
     for (auto& x : th) x.join();
+    if (failed) throw std::bad_alloc();
 }
 
 struct Bins {
