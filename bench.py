@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", type=int, default=709, help="mesh grid (709 -> 1 002 528 triangles)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-rebuilt", action="store_true", help="skip the rebuilt-BVH leg (so that a profile of k_trace_closest<true> is the near-first leg alone)")
     args = ap.parse_args()
 
     import torch
@@ -174,6 +175,8 @@ def main():
                 "pixels_within_1_lsb": float((dmax <= 1).float().mean().item()),
                 "note": "non-parity mode: children of a BVH node visited nearest first; opt-in (RT_FLAG_NEAR_FIRST)"}
         ds.set_option(RT_OPT_FLAGS, RT_FLAG_TIMING)
+        frame = exact_frame           # (fb now holds the near-first frame; the parity check is on the exact one)
+    if world == 1 and not args.no_rebuilt:
         # ... and with the library's own SAH trees over the same faces (rt_upload_scene_ex, RT_UPLOAD_REBUILD_MESH_BVH)
         t2 = time.perf_counter()
         ds2 = DeviceScene(hs, local_rank, rebuild_mesh_bvh=True)
@@ -196,13 +199,12 @@ def main():
         e2 = time.perf_counter() - t2
         dmax = (fb2.to(torch.int16) - exact_frame.to(torch.int16)).abs().amax(dim=2)
         rebuilt = {"value": rays_per_frame / (e2 / args.steps) / 1e6, "unit": "Mrays/s", "ms_per_step": e2 / args.steps * 1e3,
-                               "closest_ms_per_step": ms_c / args.steps, "shadow_ms_per_step": ms_s / args.steps,
-                               "pixels_equal_to_exact_frame": float((dmax == 0).float().mean().item()),
-                               "pixels_within_1_lsb": float((dmax <= 1).float().mean().item()),
-                               "upload_seconds": upload_s,
-                               "note": "non-parity mode: binned-SAH mesh BVHs built by the library, traced nearest first; opt-in (rt_upload_scene_ex)"}
+                   "closest_ms_per_step": ms_c / args.steps, "shadow_ms_per_step": ms_s / args.steps,
+                   "pixels_equal_to_exact_frame": float((dmax == 0).float().mean().item()),
+                   "pixels_within_1_lsb": float((dmax <= 1).float().mean().item()),
+                   "upload_seconds": upload_s,
+                   "note": "non-parity mode: binned-SAH mesh BVHs built by the library, traced nearest first; opt-in (rt_upload_scene_ex)"}
         ds2.close()
-        frame = exact_frame
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -249,6 +251,7 @@ def main():
         }
         if near is not None:
             line["near_first"] = near
+        if rebuilt is not None:
             line["rebuilt_bvh"] = rebuilt
         if world == 1 and not args.no_cpu:
             cb, parity = cpu_baseline(spec, frame.cpu().numpy() if frame is not None else None)

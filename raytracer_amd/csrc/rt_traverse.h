@@ -61,6 +61,9 @@
 #ifndef RT_LEAF_QUEUE
 #define RT_LEAF_QUEUE 8          // mesh leaves a lane may postpone before the wave switches to triangle tests
 #endif
+#ifndef RT_LEAF_QUEUE_NEAR
+#define RT_LEAF_QUEUE_NEAR RT_LEAF_QUEUE   // closest-hit rays in the near-first kernels
+#endif
 #ifndef RT_LEAF_QUEUE_ANY
 #define RT_LEAF_QUEUE_ANY 4      // same for any-hit (shadow) rays: the first accepted hit ends the ray, so postpone less
 #endif
@@ -332,7 +335,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
     constexpr bool ANY_ONLY = MODE == 1;
     bool lane_any = ANY_ONLY;
 #define RT_ISANY (MIXED ? lane_any : ANY_ONLY)
-    constexpr uint32_t QCAP = ANY_ONLY ? RT_LEAF_QUEUE_ANY : RT_LEAF_QUEUE;
+    constexpr uint32_t QCAP = ANY_ONLY ? RT_LEAF_QUEUE_ANY : (NEAR ? RT_LEAF_QUEUE_NEAR : RT_LEAF_QUEUE);
     constexpr uint32_t STRIP = ANY_ONLY ? RT_STRIP_ANY : RT_STRIP;
     constexpr uint32_t REFILL_MIN = ANY_ONLY ? RT_REFILL_MIN_ANY : RT_REFILL_MIN;
     constexpr uint32_t EXIT_FEW = ANY_ONLY ? RT_EXIT_FEW_ANY : RT_EXIT_FEW, EXIT_WAIT = ANY_ONLY ? RT_EXIT_WAIT_ANY : RT_EXIT_WAIT;

@@ -6,6 +6,8 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0]
+        if k.startswith("void "):
+            k = k[5:]                 # template instantiations are printed with their return type
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
     if not k.startswith("k_"): continue
