@@ -588,7 +588,11 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     const bool h1 = hit4[1] & (lk.y != RT_LINK_DONE);
                     const bool h2 = hit4[2] & (lk.z != RT_LINK_DONE);
                     const bool h3 = hit4[3] & (lk.w != RT_LINK_DONE);
+#ifdef RT_NEAR_TOP      // experiment: the top level nearest-first as well (outside the tolerance on overlapping objects, see below)
+                    if constexpr (NEAR && !ANY_ONLY) {
+#else
                     if constexpr (NEAR && !ANY_ONLY) if (in_mesh) {
+#endif
                         // Non-parity order (RT_FLAG_NEAR_FIRST), inside a mesh BVH only: the hit slots are visited by
                         // increasing entry distance instead of in the reference's slot order, so the bound shrinks
                         // early and more of the later boxes are culled.  All triangles of a mesh are tested against
