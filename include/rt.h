@@ -257,8 +257,9 @@ enum {
 /* Number of HIP devices visible to this process (<0: rt_status). */
 int rt_device_count(void);
 
-/* Copy the flattened scene to `device` and build the device layout (64-B node
- * pairs, 48-B leaf-ordered triangle records, per-object transform records).
+/* Copy the flattened scene to `device` and build the device layout (128-B records
+ * of four BVH grandchildren, 36-B leaf-ordered triangle records, per-object
+ * transform records).
  * Replaces nothing in the reference: it is the set-up that precedes the loop
  * at raytracer.cpp:30.  Synchronous. */
 int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out);

@@ -607,7 +607,7 @@ int build_top_level(rt_scene* sc, const rt_scene_desc* s) {
     }
     std::vector<DMaterial> mats(s->n_materials);
     sc->has_reflective = false;
-    sc->needs_sequential_rng = s->n_area_lights > 0;
+    sc->needs_sequential_rng = s->n_area_lights > 0 || getenv("RT_FORCE_ORDERED") != nullptr;   // (diagnostic: every scene through the depth-first pixel loop)
     for (uint32_t i = 0; i < s->n_materials; i++) {
         const rt_material& m = s->materials[i];
         DMaterial& d = mats[i];
