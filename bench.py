@@ -249,6 +249,11 @@ def main():
                        "partition": f"interleaved 8-row bands over {world} GPU(s), scene replicated, RGB8 rows gathered to rank 0"},
             "roofline": roofline,
         }
+        # the same algorithmic bytes (the reference's traversal) over these modes' closest-hit launches
+        for extra in (near, rebuilt):
+            if extra is not None and extra["closest_ms_per_step"] > 0:
+                extra["closest_achieved_GBps"] = bytes_closest / (extra["closest_ms_per_step"] * 1e-3) / 1e9
+                extra["closest_frac_of_hbm_peak"] = extra["closest_achieved_GBps"] / HBM_PEAK_GBS
         if near is not None:
             line["near_first"] = near
         if rebuilt is not None:
