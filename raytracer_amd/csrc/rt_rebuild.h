@@ -81,6 +81,7 @@ struct Builder {
     const float* fc;            // per face: centroid
     uint32_t* prim_face;        // this BVH's leaf order (reordered in place)
     uint32_t max_leaf;
+    float ci;                   // cost of one triangle test in units of one node step (the leaf-or-split decision)
 
     static int bin_of(float c, float lo, float scale) {
         int k = (int)((c - lo) * scale);
@@ -168,7 +169,7 @@ struct Builder {
                 if (count <= max_leaf) {
                     Box nb; std::memcpy(nb.mn, nodes[ni].bmin, 12); std::memcpy(nb.mx, nodes[ni].bmax, 12);
                     const float pa = nb.half_area();
-                    if (!(pa > 0.0f) || best_cost / pa + 1.0f >= (float)count) continue;
+                    if (!(pa > 0.0f) || ci * best_cost / pa + 1.0f >= ci * (float)count) continue;
                 }
                 uint32_t i = first, j = first + count;
                 while (i < j) {
@@ -213,7 +214,9 @@ inline void build_one(const rt_face* faces, const rt_vertex* vd, uint32_t* prim_
             for (int k = 0; k < 3; k++) fc[(size_t)f * 3 + k] = (a[k] + b[k] + c[k]) * (1.0f / 3.0f);
         }
     });
-    Builder bld{fb.data(), fc.data(), prim_face, max_leaf};
+    float ci = 1.0f;
+    if (const char* e = getenv("RT_REBUILD_TRI_COST")) ci = std::max(0.01f, (float)atof(e));
+    Builder bld{fb.data(), fc.data(), prim_face, max_leaf, ci};
     std::vector<rt_bvh_node> nodes;
     nodes.reserve(2ull * n);
     nodes.push_back(rt_bvh_node{});
