@@ -10,7 +10,9 @@
 // copy the rows back.  Built by oracle/Makefile into oracle/_ref/raytracer_hip
 // (it contains reference code, so it is not kept in the repository).
 //
-//   raytracer_hip scene.json [--gpus N] [--backend hip|cpu] [--dump-hits file]
+//   raytracer_hip scene.json [--gpus N] [--backend hip|cpu] [--dump-hits file] [--near-first] [--rebuild-bvh]
+// --near-first / --rebuild-bvh select the library's two opt-in non-parity modes (include/rt.h:
+// RT_FLAG_NEAR_FIRST, RT_UPLOAD_REBUILD_MESH_BVH); without them the PNG is the reference's, byte for byte.
 //
 // --backend cpu runs the reference's own loop (raytracer.cpp:40-87 unchanged in
 // behaviour) so both paths can be timed in the same process.
@@ -62,15 +64,18 @@ static void render_cpu(const Scene& scene, const Camera& cam, unsigned char* ima
 
 int main(int argc, char* argv[]) {
     if (argc < 2) {
-        printf("Usage: %s <scene.json> [--gpus N] [--backend hip|cpu] [--dump-hits file]\n", argv[0]);
+        printf("Usage: %s <scene.json> [--gpus N] [--backend hip|cpu] [--dump-hits file] [--near-first] [--rebuild-bvh]\n", argv[0]);
         return -1;
     }
     int gpus = 1;
     std::string backend = "hip", dump_hits;
+    bool near_first = false, rebuild_bvh = false;
     for (int i = 2; i < argc; i++) {
         if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--backend") && i + 1 < argc) backend = argv[++i];
         else if (!strcmp(argv[i], "--dump-hits") && i + 1 < argc) dump_hits = argv[++i];
+        else if (!strcmp(argv[i], "--near-first")) near_first = true;
+        else if (!strcmp(argv[i], "--rebuild-bvh")) rebuild_bvh = true;
     }
 
     double t0 = now_s();
@@ -92,7 +97,10 @@ int main(int argc, char* argv[]) {
         double a = now_s();
         dev.resize(gpus, nullptr);
         for (int g = 0; g < gpus; g++)
-            if (rt_upload_scene(g, &flat.desc, &dev[g]) != RT_OK) { fprintf(stderr, "upload: %s\n", rt_last_error()); return -1; }
+        {
+            if (rt_upload_scene_ex(g, &flat.desc, rebuild_bvh ? RT_UPLOAD_REBUILD_MESH_BVH : 0u, &dev[g]) != RT_OK) { fprintf(stderr, "upload: %s\n", rt_last_error()); return -1; }
+            if (near_first && rt_scene_set_option(dev[g], RT_OPT_FLAGS, RT_FLAG_NEAR_FIRST) != RT_OK) { fprintf(stderr, "%s\n", rt_last_error()); return -1; }
+        }
         t_upload = now_s() - a;
     }
 
