@@ -339,7 +339,8 @@ int rt_render_tile_rows_device(rt_scene* s, const rt_camera_desc* cam,
 /* Debug aid: copy `count` entries of one array of the ray-record pool, as left
  * by the last render call, to host memory.  which: 0 ray0 (origin.xyz,time; 16 B),
  * 1 ray1 (direction.xyz,live; 16 B), 2 hit0 (t,kind_index,tri,-; 16 B),
- * 3 normal+material (16 B), 4 link (child0,child1,shadow_base,flags; 16 B),
+ * 3 normal+material (16 B), 4 link (child0,child1,slot of light 0,flags | K<<8:
+ * the record's slot of light l is slot0 + l*K; 16 B),
  * 5 colour (16 B), 6 shadow_lit (1 B per shadow slot).  With one chunk and
  * num_samples == 1, record r is pixel (8*(T%tiles_per_row)+(r&7), 8*(T/tiles_per_row)+((r&63)>>3)),
  * T = r>>6, of the rendered rectangle.  No counterpart in the reference. */
