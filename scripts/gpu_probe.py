@@ -35,4 +35,5 @@ for y, x in list(zip(ys, xs))[:12]:
     print(f"px {x},{y} rec {r} gpu rgb {rgb[y,x]} ora {org[y,x]}")
     print("  ray equal:", (g.view(np.uint32) == out[:7].view(np.uint32)).all(), " t gpu/ora bits", hex(hit0[r,0]), hex(out[8:9].view(np.uint32)[0]), "kind", hit0[r,1]>>28, out[9])
     print("  n equal:", (nrm[r,:3].view(np.uint32) == out[11:14].view(np.uint32)).all(), nrm[r,:3], out[11:14])
-    print("  lit gpu", lit[sb:sb+nl], "ora", out[20:20+nl], "flags", link[r,3])
+    K = int(link[r,3]) >> 8          # the record's slot of light l is sb + l*K (k_shade: light-major inside a block)
+    print("  lit gpu", [int(lit[sb + l * K]) for l in range(nl)] if K else [], "ora", out[20:20+nl], "flags", link[r,3] & 0xFF)
