@@ -2,21 +2,26 @@
 """bench.py — headline benchmark of the MI355X ray path.
 
 Metric (BASELINE.json): Mrays/s, counting every FindClosestHit and InShadow ray.
-Workload at N=1: BASELINE.json configs[1] — a 1 002 528-triangle PLY-style mesh
-(closed-form displaced sphere) at 1920x1080, 1 spp, primary +
-shadow rays (2 point lights, MaxRecursionDepth 0).  A "step" is one frame.
-At N>1 the frame keeps the same view and grows to N x the pixels (weak scaling);
-rank r renders the interleaved 8-row bands r mod N on its own scene replica and
-the RGB8 rows are gathered to rank 0 over RCCL inside the timed region.
+
+N = 1   BASELINE.json configs[1] — a 1 002 528-triangle PLY-style mesh (closed-form displaced sphere,
+        SURVEY.md §8d M2) at 1920x1080, 1 spp, primary + shadow rays (2 point lights, MaxRecursionDepth 0).
+        A "step" is one frame.  The line also carries, as sub-objects that never enter `value`: the two opt-in
+        non-parity modes on the same frame, the CPU reference timed on the same frame with a byte-for-byte
+        comparison, and `strong_scaling_base` = the N > 1 workload rendered by this one GPU.
+N > 1   BASELINE.json configs[4] / SURVEY.md §8d M5 — the FIXED 7680x4320 frame of the 10-instance, 10 M-triangle
+        scene (mirror / dielectric / conductor, depth 6), split over the N ranks (strong scaling): rank r renders
+        the interleaved 8-row bands r mod N on its own replica of the scene, and the RGB8 rows are gathered to
+        rank 0 over RCCL inside the timed region.  `weak` holds the weak-scaling figure of earlier rounds
+        (configs[1] with N x the pixels).
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  Inputs (scene, ray pools) are resident in HBM
-before the timed region; the frame stays on the device.
+Rank 0 prints ONE JSON line.  Inputs (scene, ray pools) are resident in HBM before the timed region; the frame
+stays on the device.
 """
 import argparse
-import ctypes
+import hashlib
 import json
 import math
 import os
@@ -27,12 +32,27 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MALL_GATHER_GBS = 8600.0     # same guide, 'Indexed rows': 38 MB table gathered from the Infinity Cache, chip-wide
+L2_GATHER_GBS = 17800.0      # same table: rows shared by every workgroup, served by the XCDs' L2 (16.8-18.8 TB/s)
+STRONG_W, STRONG_H = 7680, 4320
 
 
-def frame_size(n_gpus):
+def weak_frame_size(n_gpus):
     s = math.sqrt(n_gpus)
     return int(round(1920 * s / 8)) * 8, int(round(1080 * s / 8)) * 8
+
+
+def csrc_sha16():
+    """Identity of the kernel sources the library was built from (the GPU box has no .git): profiles/pmc_traffic.json
+    records it, and counters taken on other sources are not quoted."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "raytracer_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(scene_spec, gpu_rgb):
@@ -73,6 +93,124 @@ def cpu_baseline(scene_spec, gpu_rgb):
     return out, parity
 
 
+class Run:
+    """One scene resident on this rank's GPU + its share of one frame; timed() runs W + K steps."""
+
+    def __init__(self, env, spec, rebuild=False, flags=0, hs=None):
+        from raytracer_amd import DeviceScene, RT_OPT_FLAGS, RT_FLAG_TIMING
+        import torch
+        self.env = env
+        self.spec = spec
+        self.hs = hs if hs is not None else spec.build()
+        self.cam = self.hs.camera(0)
+        self.W, self.H = self.cam.image_width, self.cam.image_height
+        t = time.perf_counter()
+        self.ds = DeviceScene(self.hs, env.local_rank, rebuild_mesh_bvh=rebuild)
+        self.upload_seconds = time.perf_counter() - t
+        self.ds.set_option(RT_OPT_FLAGS, RT_FLAG_TIMING | flags)
+        self.fb = torch.zeros((self.H, self.W, 3), dtype=torch.uint8, device=env.dev)
+
+    def step(self, st=None):
+        from raytracer_amd import multigpu
+        e = self.env
+        self.ds.render_rows_device(self.cam, 0, 0, self.W, self.H, e.world, e.rank, self.fb.data_ptr(), self.W * 3, stats=st, stream=e.stream)
+        return multigpu.gather_frame(self.fb, e.rank, e.world)
+
+    def timed(self, steps, warmup):
+        import torch
+        import torch.distributed as dist
+        from raytracer_amd import Stats
+        e = self.env
+        for _ in range(warmup):
+            self.step(Stats())
+        acc = {k: 0.0 for k in ("raygen", "closest", "shade", "shadow", "combine", "resolve")}
+        acc.update(n_closest=0, n_shadow=0)
+        rays = [0, 0, 0]
+        e.fence()
+        t0 = time.perf_counter()
+        frame = None
+        for _ in range(steps):
+            st = Stats()
+            frame = self.step(st)
+            for k in ("raygen", "closest", "shade", "shadow", "combine", "resolve"):
+                acc[k] += getattr(st, "ms_" + k)
+            acc["n_closest"] += st.launches_closest
+            acc["n_shadow"] += st.launches_shadow
+            rays = [st.rays_primary, st.rays_secondary, st.rays_shadow]
+        e.fence()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=e.dev)
+        r = torch.tensor(rays, dtype=torch.float64, device=e.dev)
+        if e.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)          # the slowest rank's clock
+            dist.all_reduce(r, op=dist.ReduceOp.SUM)          # rays of all ranks
+        return {"elapsed": float(t.item()), "rays_frame": [float(v) for v in r.tolist()], "rays_rank": rays, "acc": acc,
+                "frame": frame, "steps": steps}
+
+    def close(self):
+        self.ds.close()
+
+
+class Env:
+    pass
+
+
+def pmc_block(workload_key, kernel):
+    """Counters of `kernel` on `workload_key` from the committed rocprofv3 --pmc passes (scripts/pmc.sh ->
+    scripts/pmc_to_json.py) — quoted only if they were taken on these very kernel sources."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pt = json.load(f)
+        if pt.get("csrc_sha16") != csrc_sha16():
+            return None
+        return pt[workload_key][kernel]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def roofline_single(acc, rays, wb, workload_key):
+    """N = 1, depth 0: one closest-hit and one any-hit launch per frame; the longer one is the dominant kernel."""
+    dur_closest = acc["closest"] / max(acc["n_closest"], 1) * 1e-3
+    dur_shadow = acc["shadow"] / max(acc["n_shadow"], 1) * 1e-3
+    bytes_closest = wb["closest_bytes_per_ray"] * rays[0]
+    bytes_shadow = wb["shadow_bytes_per_ray"] * rays[2]
+    dom = "k_trace_closest" if dur_closest >= dur_shadow else "k_trace_shadow"
+    dom_bytes, dom_dur = (bytes_closest, dur_closest) if dom == "k_trace_closest" else (bytes_shadow, dur_shadow)
+    oth_bytes, oth_dur = (bytes_shadow, dur_shadow) if dom == "k_trace_closest" else (bytes_closest, dur_closest)
+    pm = pmc_block(workload_key, dom)
+    ach = dom_bytes / dom_dur / 1e9
+    r = {
+        "bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+        # bytes per launch at the fabric side of L2, FETCH_SIZE corrected as the microarch guide prescribes
+        # (profiles/pmc_traffic.json); null when the committed counters were taken on other kernel sources
+        "traffic": pm["hbm_bytes_per_launch"] if pm else None,
+        "algorithmic_bytes_per_launch": dom_bytes,
+        "algorithmic_bytes_per_ray": wb["closest_bytes_per_ray"] if dom == "k_trace_closest" else wb["shadow_bytes_per_ray"],
+        "rays_per_launch": rays[0] if dom == "k_trace_closest" else rays[2],
+        "avg_launch_ms": dom_dur * 1e3,
+        # The working set (66 MB) lives in L2 / Infinity Cache, so the HBM fraction is not the roof that binds; the
+        # same algorithmic bytes against the cache gather rates the guide measured:
+        "cache_roofline": {"achieved": ach, "unit": "GB/s", "mall_gather_peak": MALL_GATHER_GBS, "frac_of_mall_gather": ach / MALL_GATHER_GBS,
+                           "l2_gather_peak": L2_GATHER_GBS, "frac_of_l2_gather": ach / L2_GATHER_GBS},
+        "other_kernel": {"kernel": "k_trace_shadow" if dom == "k_trace_closest" else "k_trace_closest",
+                         "achieved": oth_bytes / oth_dur / 1e9 if oth_dur > 0 else None, "avg_launch_ms": oth_dur * 1e3},
+    }
+    # what binds instead (VALU issue at partial lane occupancy): from the PMC passes, same condition as `traffic`
+    for k in ("valu_issue_util", "waves_per_simd", "lane_occupancy", "l2_hit_rate", "valu_insts_per_launch"):
+        r[k] = pm.get(k) if pm else None
+    return r, bytes_closest
+
+
+def roofline_all_traces(acc, rays_rank, wb):
+    """Depth > 0: a frame is a chain of trace launches (k_trace_closest for generation 0, then one k_trace_mixed per
+    bounce, a last k_trace_shadow): the figure is over all of them on this rank — algorithmic bytes of the rays
+    this rank traced over the summed launch time (bytes per launch over the average launch: the same ratio)."""
+    n_launch = acc["n_closest"] + acc["n_shadow"]
+    dur = (acc["closest"] + acc["shadow"]) * 1e-3
+    steps_bytes = wb["closest_bytes_per_ray"] * (rays_rank[0] + rays_rank[1]) + wb["shadow_bytes_per_ray"] * rays_rank[2]
+    return n_launch, dur, steps_bytes
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,191 +219,151 @@ def main():
     ap.add_argument("--grid", type=int, default=709, help="mesh grid (709 -> 1 002 528 triangles)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-rebuilt", action="store_true", help="skip the rebuilt-BVH leg (so that a profile of k_trace_closest<true> is the near-first leg alone)")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the non-parity legs and the strong-scaling base; N > 1: skip the weak-scaling leg")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from raytracer_amd import DeviceScene, Stats, RT_OPT_FLAGS, RT_FLAG_TIMING, RT_FLAG_NEAR_FIRST, scenes, multigpu
+    from raytracer_amd import RT_FLAG_NEAR_FIRST, scenes
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    e = Env()
+    e.rank = int(os.environ.get("RANK", "0"))
+    e.world = int(os.environ.get("WORLD_SIZE", "1"))
+    e.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if e.world != args.gpus and e.world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={e.world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     # Rehearsal on a 1-GPU box: RT_BENCH_REHEARSE=1 puts every rank on GPU 0 and uses gloo (RCCL refuses two
     # ranks on one device).  Never set by the driver; real runs are one rank per GPU over RCCL.
     rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
     if rehearse:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
+        e.local_rank = 0
+    torch.cuda.set_device(e.local_rank)
+    e.dev = torch.device("cuda", e.local_rank)
+    if e.world > 1:
         if rehearse:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
-
-    W, H = frame_size(world)
-    spec = scenes.mesh_scene(args.grid, W, H)
-    hs = spec.build()
-    cam = hs.camera(0)
-    ds = DeviceScene(hs, local_rank)
-    ds.set_option(RT_OPT_FLAGS, RT_FLAG_TIMING)
-    fb = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step(st=None):
-        ds.render_rows_device(cam, 0, 0, W, H, world, rank, fb.data_ptr(), W * 3, stats=st, stream=stream)
-        return multigpu.gather_frame(fb, rank, world)
-
-    for _ in range(args.warmup):
-        step(Stats())
+            dist.init_process_group("nccl", device_id=e.dev)
+    e.stream = torch.cuda.current_stream().cuda_stream
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if e.world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+    e.fence = fence
 
-    acc = {"closest": 0.0, "shadow": 0.0, "n_closest": 0, "n_shadow": 0, "raygen": 0.0, "shade": 0.0, "combine": 0.0, "resolve": 0.0}
-    rays = [0, 0, 0]
-    fence()
-    t0 = time.perf_counter()
-    frame = None
-    for _ in range(args.steps):
-        st = Stats()
-        frame = step(st)
-        acc["closest"] += st.ms_closest; acc["shadow"] += st.ms_shadow
-        acc["n_closest"] += st.launches_closest; acc["n_shadow"] += st.launches_shadow
-        acc["raygen"] += st.ms_raygen; acc["shade"] += st.ms_shade; acc["combine"] += st.ms_combine; acc["resolve"] += st.ms_resolve
-        rays = [st.rays_primary, st.rays_secondary, st.rays_shadow]
-    fence()
-    elapsed = time.perf_counter() - t0
+    with open(os.path.join(ROOT, "profiles", "workload_bytes.json")) as f:
+        wb_all = json.load(f)
+    strong_w, strong_h = (STRONG_W, STRONG_H) if args.grid == 709 else (1920, 1080)   # (--grid: rehearsals at a smaller size)
+    line = None
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    r = torch.tensor(rays, dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    rays_per_frame = float(r.sum().item())
-
-    # The same frames in the non-parity visiting order (RT_FLAG_NEAR_FIRST, include/rt.h) — reported beside the
-    # headline, never as `value`; compared with the exact frame pixel by pixel.
-    near = rebuilt = None
-    if world == 1:
-        exact_frame = frame.clone()
-        ds.set_option(RT_OPT_FLAGS, RT_FLAG_TIMING | RT_FLAG_NEAR_FIRST)
-        step(Stats())
-        fence()
-        t1 = time.perf_counter()
-        ms_c = 0.0
-        for _ in range(args.steps):
-            st = Stats()
-            nf = step(st)
-            ms_c += st.ms_closest
-        fence()
-        e1 = time.perf_counter() - t1
-        dmax = (nf.to(torch.int16) - exact_frame.to(torch.int16)).abs().amax(dim=2)
-        near = {"value": rays_per_frame / (e1 / args.steps) / 1e6, "unit": "Mrays/s", "ms_per_step": e1 / args.steps * 1e3,
-                "closest_ms_per_step": ms_c / args.steps,
-                "pixels_equal_to_exact_frame": float((dmax == 0).float().mean().item()),
-                "pixels_within_1_lsb": float((dmax <= 1).float().mean().item()),
-                "note": "non-parity mode: children of a BVH node visited nearest first; opt-in (RT_FLAG_NEAR_FIRST)"}
-        ds.set_option(RT_OPT_FLAGS, RT_FLAG_TIMING)
-        frame = exact_frame           # (fb now holds the near-first frame; the parity check is on the exact one)
-    if world == 1 and not args.no_rebuilt:
-        # ... and with the library's own SAH trees over the same faces (rt_upload_scene_ex, RT_UPLOAD_REBUILD_MESH_BVH)
-        t2 = time.perf_counter()
-        ds2 = DeviceScene(hs, local_rank, rebuild_mesh_bvh=True)
-        upload_s = time.perf_counter() - t2
-        ds2.set_option(RT_OPT_FLAGS, RT_FLAG_TIMING)
-        fb2 = torch.zeros_like(fb)
-
-        def step2(st):
-            ds2.render_rows_device(cam, 0, 0, W, H, world, rank, fb2.data_ptr(), W * 3, stats=st, stream=stream)
-
-        step2(Stats())
-        fence()
-        t2 = time.perf_counter()
-        ms_c = ms_s = 0.0
-        for _ in range(args.steps):
-            st = Stats()
-            step2(st)
-            ms_c += st.ms_closest; ms_s += st.ms_shadow
-        fence()
-        e2 = time.perf_counter() - t2
-        dmax = (fb2.to(torch.int16) - exact_frame.to(torch.int16)).abs().amax(dim=2)
-        rebuilt = {"value": rays_per_frame / (e2 / args.steps) / 1e6, "unit": "Mrays/s", "ms_per_step": e2 / args.steps * 1e3,
-                   "closest_ms_per_step": ms_c / args.steps, "shadow_ms_per_step": ms_s / args.steps,
-                   "pixels_equal_to_exact_frame": float((dmax == 0).float().mean().item()),
-                   "pixels_within_1_lsb": float((dmax <= 1).float().mean().item()),
-                   "upload_seconds": upload_s,
-                   "note": "non-parity mode: binned-SAH mesh BVHs built by the library, traced nearest first; opt-in (rt_upload_scene_ex)"}
-        ds2.close()
-
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = rays_per_frame / (elapsed / args.steps) / 1e6
-        with open(os.path.join(ROOT, "profiles", "workload_bytes.json")) as f:
-            wb = json.load(f)["mesh1m_1920x1080"]
-        # dominant kernel: the closest-hit traversal (one launch per frame at depth 0)
-        dur_closest = acc["closest"] / max(acc["n_closest"], 1) * 1e-3
-        dur_shadow = acc["shadow"] / max(acc["n_shadow"], 1) * 1e-3
-        bytes_closest = wb["closest_bytes_per_ray"] * rays[0]
-        bytes_shadow = wb["shadow_bytes_per_ray"] * rays[2]
-        dom = "k_trace_closest" if dur_closest >= dur_shadow else "k_trace_shadow"
-        # HBM-side bytes per launch of that kernel, from the committed rocprofv3 --pmc passes of this same
-        # command (a bench run cannot collect counters itself); only quoted for the workload they were taken on
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pt = json.load(f)
-            if world == 1 and args.grid == 709:
-                traffic = pt["mesh1m_1920x1080"][dom]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            traffic = None
-        ach = (bytes_closest / dur_closest if dom == "k_trace_closest" else bytes_shadow / dur_shadow) / 1e9
-        roofline = {
-            "bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": traffic,   # bytes per launch, FETCH_SIZE corrected as the microarch guide prescribes (profiles/pmc_traffic.json)
-            "algorithmic_bytes_per_launch": bytes_closest if dom == "k_trace_closest" else bytes_shadow,
-            "algorithmic_bytes_per_ray": wb["closest_bytes_per_ray"] if dom == "k_trace_closest" else wb["shadow_bytes_per_ray"],
-            "rays_per_launch": rays[0] if dom == "k_trace_closest" else rays[2],
-            "avg_launch_ms": (dur_closest if dom == "k_trace_closest" else dur_shadow) * 1e3,
-            "other_kernel": {"kernel": "k_trace_shadow" if dom == "k_trace_closest" else "k_trace_closest",
-                             "achieved": (bytes_shadow / dur_shadow if dom == "k_trace_closest" else bytes_closest / dur_closest) / 1e9 if min(dur_closest, dur_shadow) > 0 else None,
-                             "avg_launch_ms": (dur_shadow if dom == "k_trace_closest" else dur_closest) * 1e3},
-            "stage_ms_per_step": {k: acc[k] / args.steps for k in ("raygen", "closest", "shade", "shadow", "combine", "resolve")},
-        }
+    if e.world == 1:
+        # ------------------------------------------------------------------ N = 1: configs[1]
+        spec = scenes.mesh_scene(args.grid, 1920, 1080)
+        run = Run(e, spec)
+        res = run.timed(args.steps, args.warmup)
+        rays = res["rays_rank"]
+        rays_per_frame = sum(res["rays_frame"])
+        ms_per_step = res["elapsed"] / args.steps * 1e3
+        value = rays_per_frame / (res["elapsed"] / args.steps) / 1e6
+        acc = res["acc"]
+        exact_frame = res["frame"].clone()
+        roofline, bytes_closest = roofline_single(acc, rays, wb_all["mesh1m_1920x1080"], "mesh1m_1920x1080" if args.grid == 709 else "-")
+        roofline["stage_ms_per_step"] = {k: acc[k] / args.steps for k in ("raygen", "closest", "shade", "shadow", "combine", "resolve")}
         line = {
-            "metric": "Mrays/s (primary+secondary+shadow)", "value": value, "unit": "Mrays/s", "n_gpus": world,
+            "metric": "Mrays/s (primary+secondary+shadow)", "value": value, "unit": "Mrays/s", "n_gpus": 1,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"mesh1m: {2 * (args.grid - 1) ** 2}-triangle mesh, {W}x{H}, 1 spp, primary + shadow rays (2 point lights), depth 0",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"mesh1m: {2 * (args.grid - 1) ** 2}-triangle mesh, 1920x1080, 1 spp, primary + shadow rays (2 point lights), depth 0",
                        "rays_per_frame": rays_per_frame, "seconds_per_frame": ms_per_step / 1e3,
-                       "partition": f"interleaved 8-row bands over {world} GPU(s), scene replicated, RGB8 rows gathered to rank 0"},
+                       "partition": "one GPU, whole frame; N > 1 runs BASELINE configs[4] (see strong_scaling_base)"},
             "roofline": roofline,
         }
-        # the same algorithmic bytes (the reference's traversal) over these modes' closest-hit launches
-        for extra in (near, rebuilt):
-            if extra is not None and extra["closest_ms_per_step"] > 0:
-                extra["closest_achieved_GBps"] = bytes_closest / (extra["closest_ms_per_step"] * 1e-3) / 1e9
-                extra["closest_frac_of_hbm_peak"] = extra["closest_achieved_GBps"] / HBM_PEAK_GBS
-        if near is not None:
-            line["near_first"] = near
-        if rebuilt is not None:
-            line["rebuilt_bvh"] = rebuilt
-        if world == 1 and not args.no_cpu:
-            cb, parity = cpu_baseline(spec, frame.cpu().numpy() if frame is not None else None)
+        if not args.no_extras:
+            # The same frames in the non-parity visiting order (RT_FLAG_NEAR_FIRST, include/rt.h) — reported beside
+            # the headline, never as `value`; compared with the exact frame pixel by pixel.
+            def extra_leg(r, note):
+                x = r.timed(args.steps, 1)
+                dmax = (x["frame"].to(torch.int16) - exact_frame.to(torch.int16)).abs().amax(dim=2)
+                ms_c = x["acc"]["closest"] / args.steps
+                out = {"value": rays_per_frame / (x["elapsed"] / args.steps) / 1e6, "unit": "Mrays/s", "ms_per_step": x["elapsed"] / args.steps * 1e3,
+                       "closest_ms_per_step": ms_c, "shadow_ms_per_step": x["acc"]["shadow"] / args.steps,
+                       "pixels_equal_to_exact_frame": float((dmax == 0).float().mean().item()),
+                       "pixels_within_1_lsb": float((dmax <= 1).float().mean().item()), "note": note}
+                if ms_c > 0:   # the same algorithmic bytes (the reference's traversal) over this mode's closest-hit launches
+                    out["closest_achieved_GBps"] = bytes_closest / (ms_c * 1e-3) / 1e9
+                    out["closest_frac_of_hbm_peak"] = out["closest_achieved_GBps"] / HBM_PEAK_GBS
+                return out
+            r2 = Run(e, spec, flags=RT_FLAG_NEAR_FIRST, hs=run.hs)
+            line["near_first"] = extra_leg(r2, "non-parity mode: children of a BVH node visited nearest first; opt-in (RT_FLAG_NEAR_FIRST)")
+            r2.close()
+            if not args.no_rebuilt:
+                r3 = Run(e, spec, rebuild=True, hs=run.hs)
+                line["rebuilt_bvh"] = extra_leg(r3, "non-parity mode: binned-SAH mesh BVHs built by the library, traced nearest first; opt-in (rt_upload_scene_ex)")
+                line["rebuilt_bvh"]["upload_seconds"] = r3.upload_seconds
+                r3.close()
+            # the workload of the N > 1 runs on this one GPU: the base of the strong-scaling curve
+            rs = Run(e, scenes.instanced_scene(args.grid, strong_w, strong_h))
+            k = max(2, min(5, args.steps))
+            x = rs.timed(k, 1)
+            n_launch, dur, bts = roofline_all_traces(x["acc"], x["rays_rank"], wb_all["inst10_7680x4320"])
+            line["strong_scaling_base"] = {
+                "workload": f"inst10: 10 instances of the {2 * (args.grid - 1) ** 2}-triangle mesh, {strong_w}x{strong_h}, 1 spp, depth 6 (BASELINE configs[4])",
+                "value": sum(x["rays_frame"]) / (x["elapsed"] / k) / 1e6, "unit": "Mrays/s", "n_gpus": 1, "steps": k,
+                "ms_per_step": x["elapsed"] / k * 1e3, "seconds_per_frame": x["elapsed"] / k, "rays_per_frame": sum(x["rays_frame"]),
+                "trace_launches_per_frame": n_launch / k,
+                "trace_achieved_GBps": bts / dur / 1e9 if dur > 0 else None, "trace_frac_of_hbm_peak": bts / dur / 1e9 / HBM_PEAK_GBS if dur > 0 else None}
+            rs.close()
+        if not args.no_cpu:
+            cb, parity = cpu_baseline(spec, exact_frame.cpu().numpy())
             line["cpu_baseline"] = cb
             if parity:
                 line["parity_vs_cpu_reference"] = parity
+        run.close()
+    else:
+        # ------------------------------------------------------------------ N > 1: configs[4], strong scaling
+        spec = scenes.instanced_scene(args.grid, strong_w, strong_h)
+        run = Run(e, spec)
+        res = run.timed(args.steps, args.warmup)
+        rays_per_frame = sum(res["rays_frame"])
+        ms_per_step = res["elapsed"] / args.steps * 1e3
+        value = rays_per_frame / (res["elapsed"] / args.steps) / 1e6
+        n_launch, dur, bts = roofline_all_traces(res["acc"], res["rays_rank"], wb_all["inst10_7680x4320"])
+        run.close()
+        weak = None
+        if not args.no_extras:
+            W, H = weak_frame_size(e.world)
+            rw = Run(e, scenes.mesh_scene(args.grid, W, H))
+            k = max(2, min(10, args.steps))
+            x = rw.timed(k, 1)
+            weak = {"workload": f"mesh1m at {W}x{H} (configs[1] with {e.world} x the pixels)", "scaling": "weak",
+                    "value": sum(x["rays_frame"]) / (x["elapsed"] / k) / 1e6, "unit": "Mrays/s", "ms_per_step": x["elapsed"] / k * 1e3, "steps": k}
+            rw.close()
+        if e.rank == 0:
+            ach = bts / dur / 1e9 if dur > 0 else 0.0
+            line = {
+                "metric": "Mrays/s (primary+secondary+shadow)", "value": value, "unit": "Mrays/s", "n_gpus": e.world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"inst10: 10 instances of the {2 * (args.grid - 1) ** 2}-triangle mesh (mirror / dielectric / conductor), {strong_w}x{strong_h}, 1 spp, depth 6 (BASELINE configs[4])",
+                           "rays_per_frame": rays_per_frame, "seconds_per_frame": ms_per_step / 1e3,
+                           "partition": f"fixed frame; interleaved 8-row bands over {e.world} GPUs, scene replicated, RGB8 rows gathered to rank 0 (one gather, {strong_w * strong_h * 3} bytes in all)",
+                           "single_gpu_figure": "the N = 1 line's strong_scaling_base is this workload on one GPU"},
+                "roofline": {"bound": "hbm", "kernel": "all trace launches of rank 0 (k_trace_closest, k_trace_mixed per bounce, k_trace_shadow)",
+                             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                             "launches_per_frame": n_launch / args.steps, "avg_launch_ms": dur * 1e3 / max(n_launch, 1),
+                             "algorithmic_bytes_per_launch": bts / max(n_launch, 1),
+                             "cache_roofline": {"achieved": ach, "unit": "GB/s", "mall_gather_peak": MALL_GATHER_GBS, "frac_of_mall_gather": ach / MALL_GATHER_GBS},
+                             "stage_ms_per_step": {k: res["acc"][k] / args.steps for k in ("raygen", "closest", "shade", "shadow", "combine", "resolve")}},
+            }
+            if weak:
+                line["weak"] = weak
+    if e.rank == 0 and line is not None:
         print(json.dumps(line), flush=True)
-    ds.close()
-    if world > 1:
+    if e.world > 1:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -251,7 +251,11 @@ enum {
     RT_OPT_FLAGS          = 1,  /* bitmask of RT_FLAG_*                            */
     RT_OPT_POOL_RECORDS   = 2,  /* upper bound of the ray-record pool (records, ~104 B each; default 256 M):
                                    a render allocates four records per sample of its largest chunk, up to this */
-    RT_OPT_CHUNK_SAMPLES  = 3   /* max pixel-samples started per chunk (default 64 M) */
+    RT_OPT_CHUNK_SAMPLES  = 3,  /* max pixel-samples started per chunk (default 64 M) */
+    RT_OPT_STACK_CAP      = 4   /* DIAGNOSTIC: traversal stack entries per ray instead of what the upload derived from the
+                                   scene's BVH depths (>= 64, so that every BVH the reference can walk with its stack[64],
+                                   raytracer.cpp:533,766, fits); tests use it to provoke RT_ERR_OVERFLOW.  0 = derived value
+                                   again at the next rt_update_scene */
 };
 
 /* Number of HIP devices visible to this process (<0: rt_status). */
@@ -313,8 +317,12 @@ int rt_render_tile(rt_scene* s, const rt_camera_desc* cam,
 /* Same, but rgb_out / hit_id_out are DEVICE pointers on the scene's GPU and the
  * work is enqueued on `hip_stream` (a hipStream_t passed as void*; NULL = the
  * scene's own stream).  Returns after enqueueing unless stats != NULL or
- * RT_FLAG_TIMING is set, in which case it synchronises the stream to fill
- * stats.  Used for multi-GPU frames: every GPU renders its tiles into its own
+ * RT_FLAG_TIMING is set (or the scene spawns child rays / draws random numbers
+ * while shading), in which case it synchronises the stream to fill stats.
+ * When it returns early, a failure the kernels detect (RT_ERR_OVERFLOW, an
+ * internal bound) is not lost: it is returned — once — by rt_sync() or by
+ * the next render / update call on this scene, and the frame that render
+ * wrote is then not to be used.  Used for multi-GPU frames: every GPU renders its tiles into its own
  * device framebuffer and only that framebuffer is gathered (xGMI). */
 int rt_render_tile_device(rt_scene* s, const rt_camera_desc* cam,
                           int x0, int y0, int tile_w, int tile_h,
@@ -346,7 +354,9 @@ int rt_render_tile_rows_device(rt_scene* s, const rt_camera_desc* cam,
  * T = r>>6, of the rendered rectangle.  No counterpart in the reference. */
 int rt_debug_fetch(rt_scene* s, int which, uint64_t first, uint64_t count, void* out);
 
-/* Wait for everything enqueued on the scene's stream. */
+/* Wait for everything enqueued on the scene's stream and for the last render
+ * that returned before its kernels ran (also one enqueued on a caller's
+ * stream); returns that render's failure, if any (see rt_render_tile_device). */
 int rt_sync(rt_scene* s);
 
 void rt_free_scene(rt_scene* s);

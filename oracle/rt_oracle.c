@@ -7,7 +7,7 @@
  * this library, and only as the checker.  The product (librt_hip.so) never
  * links, loads or calls it.
  *
- * Parity status: PINNED.  tests/test_oracle_vs_reference.py checks that this
+ * Parity status: PINNED.  tests/test_oracle.py checks that this
  * file reproduces, byte for byte, (a) the reference's own committed renders
  * blog/hw3/my_outputs/{spheres_dof,cornellbox_area,cornellbox_brushed_metal,
  * metal_glass_plates,cornellbox_boxes_dynamic}.png, from_hw2/{mirror_room,

@@ -110,6 +110,7 @@ struct DScene {
     const DPointLight* point_lights;
     const DBigLeaf*   big_leaves;    // sorted by first; mesh and top-level leaves share the table (top entries have bit31 of first set)
     uint32_t n_big_leaves;
+    uint32_t stack_cap;   // traversal stack entries per ray (>= RT_STACK_MIN_CAP; covers the BVH depths of this scene)
     uint32_t donate_ok;   // every mesh BVH visits its leaves in ascending triangle-slot order (needed by subtree donation)
     uint32_t n_planes, n_point_lights, n_materials;
     uint32_t top_root_link;

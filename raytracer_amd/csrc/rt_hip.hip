@@ -125,6 +125,16 @@ struct rt_scene {
     // timing events
     struct Ev { hipEvent_t a, b; int cat; };
     std::vector<Ev> ev_used, ev_free;
+    hipEvent_t ev_total_a = nullptr, ev_total_b = nullptr;   // rt_stats.ms_total (created at upload, reused)
+
+    // A render that returned before its kernels ran (rt_render_tile_device without stats) leaves its Control block
+    // in h_ctl behind ev_async; rt_sync and the next render / update call look at it (check_async).
+    hipEvent_t ev_async = nullptr;
+    bool pending_check = false;
+
+    // deepest traversal stack any ray of this scene can need (entries), from the BVH depths found at upload
+    uint32_t mesh_stack_need = 0, stack_cap = RT_STACK_MIN_CAP;
+    uint32_t stack_cap_override = 0;   // RT_OPT_STACK_CAP (diagnostic)
 };
 
 namespace {
@@ -132,22 +142,49 @@ namespace {
 // ---------------------------------------------------------------- validation
 int validate_bvh(const rt_bvh_node* nodes, uint32_t count, uint32_t n_prims, const char* what) {
     if (count == 0) return RT_OK;
-    std::vector<uint8_t> covered(n_prims, 0);
+    // The node array must be a TREE over all `count` nodes, as the reference's builders produce it (root 0,
+    // children allocated pairwise after their parent, nodesUsed counts exactly the nodes reachable:
+    // raytracer.cpp:11,189-190,323-324): node 0 has no parent, every other node exactly one.  The upload
+    // relies on it — the device-side collapse (rt_upload.h) reads every node's parent link and reserves
+    // count/2 + 1 records, and a shared child (a DAG) would make the host walks exponential.
+    std::vector<uint8_t> parents(count, 0);
     for (uint32_t i = 0; i < count; i++) {
         const rt_bvh_node& n = nodes[i];
         if (n.prim_count > 0) {
             if (n.left_or_first < 0 || (uint64_t)n.left_or_first + (uint64_t)n.prim_count > n_prims)
                 return fail(RT_ERR_INVALID, "%s: leaf %u range out of bounds", what, i);
         } else if (n.prim_count == 0) {
-            // children are allocated after their parent (raytracer.cpp:189-190, 323-324): enforcing it
-            // guarantees the device traversal terminates
+            // children are allocated after their parent: enforcing it guarantees the device traversal terminates
             if (n.left_or_first <= (int32_t)i || (uint32_t)n.left_or_first + 1 >= count)
                 return fail(RT_ERR_INVALID, "%s: interior node %u has bad children", what, i);
+            for (uint32_t c = (uint32_t)n.left_or_first; c <= (uint32_t)n.left_or_first + 1; c++)
+                if (++parents[c] > 1) return fail(RT_ERR_INVALID, "%s: node %u has more than one parent", what, c);
         } else {
             return fail(RT_ERR_INVALID, "%s: node %u has negative prim_count", what, i);
         }
     }
+    for (uint32_t i = 1; i < count; i++)
+        if (parents[i] != 1) return fail(RT_ERR_INVALID, "%s: node %u is not referenced by any interior node", what, i);
     return RT_OK;
+}
+
+// Depth of a validated BVH (edges from the root to its deepest node).  Children follow their parent in the
+// array, so one forward pass does it.
+uint32_t bvh_depth(const rt_bvh_node* nodes, uint32_t count) {
+    std::vector<uint32_t> depth(count, 0);
+    uint32_t deepest = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        if (nodes[i].prim_count != 0) continue;
+        const uint32_t c = (uint32_t)nodes[i].left_or_first, d = depth[i] + 1;
+        depth[c] = depth[c + 1] = d;
+        deepest = std::max(deepest, d);
+    }
+    return deepest;
+}
+// Stack entries the traversal of rt_traverse.h can hold at once for a BVH of that depth: a node record covers two
+// reference levels and leaves up to three pending siblings behind.  (The reference's own walk keeps one sibling
+// per level, at most depth + 1 of its stack[64], raytracer.cpp:533,766.)
+uint32_t stack_need_of_depth(uint32_t depth) { return 3u * ((depth + 1u) / 2u);
 }
 
 int validate_scene(const rt_scene_desc* s, bool mesh_geometry = true) {
@@ -462,10 +499,14 @@ int build_mesh_level(rt_scene* sc, const rt_scene_desc* s) {
         if (!converged) return fail(RT_ERR_INVALID, "mesh BVH %u is deeper than 4096 levels", b);
         k_collapse_flag_scan<<<nb, RT_COLLAPSE_BLOCK, 0, sc->stream>>>(dref, anc[cur], n, (uint32_t*)d_local.p, (uint32_t*)d_sums.p);
         k_collapse_scan_sums<<<1, RT_COLLAPSE_BLOCK, 0, sc->stream>>>((uint32_t*)d_sums.p, nb, word + 1);
-        k_collapse_emit<<<grid, 256, 0, sc->stream>>>(dref, (const uint32_t*)d_local.p, (const uint32_t*)d_sums.p, n, mb.prim_offset, rec_count,
-                                                      (DNode4*)sc->b_nodes.p);
         uint32_t n_rec = 0;
         HIPCHK(hipMemcpyAsync(&n_rec, word + 1, 4, hipMemcpyDeviceToHost, sc->stream));
+        HIPCHK(hipStreamSynchronize(sc->stream));
+        // a tree of n nodes has at most n / 2 interior nodes, hence record roots (validate_bvh established the
+        // tree); never let the emit kernel write beyond what this BVH reserved in the node array
+        if (n_rec > n / 2 + 1) return fail(RT_ERR_INVALID, "mesh BVH %u: %u node records for %u nodes (not a tree)", b, n_rec, n);
+        k_collapse_emit<<<grid, 256, 0, sc->stream>>>(dref, (const uint32_t*)d_local.p, (const uint32_t*)d_sums.p, n, mb.prim_offset, rec_count,
+                                                      (DNode4*)sc->b_nodes.p);
         HIPCHK(hipStreamSynchronize(sc->stream));
         HIPCHK(hipGetLastError());
         BvhLayout& L = mesh_layout[b];
@@ -486,9 +527,12 @@ int build_mesh_level(rt_scene* sc, const rt_scene_desc* s) {
     }
     if ((rc = flush_host_records())) return rc;
     pc.lap("mesh BVH collapse");
-    for (uint32_t b = 0; b < s->n_mesh_bvhs; b++)
+    sc->mesh_stack_need = 0;
+    for (uint32_t b = 0; b < s->n_mesh_bvhs; b++) {
         if (!leaves_ascending(s->mesh_nodes + s->mesh_bvhs[b].node_offset, s->mesh_bvhs[b].node_count)) donate_ok = false;
-    pc.lap("leaf order check (host)");
+        sc->mesh_stack_need = std::max(sc->mesh_stack_need, stack_need_of_depth(bvh_depth(s->mesh_nodes + s->mesh_bvhs[b].node_offset, s->mesh_bvhs[b].node_count)));
+    }
+    pc.lap("leaf order + depth (host)");
     // triangle records, shading records and vertex normals: gathered on the device from the caller's arrays
     if ((rc = sc->b_tris.ensure(std::max<size_t>(s->n_mesh_prims, 1) * sizeof(DTri))) ||
         (rc = sc->b_tri_shade.ensure(std::max<size_t>(s->n_mesh_prims, 1) * sizeof(DTriShade))) ||
@@ -594,6 +638,11 @@ int build_top_level(rt_scene* sc, const rt_scene_desc* s) {
         for (int32_t k = 0; k < n.prim_count; k++) top[n.left_or_first + k].remaining = (uint32_t)(n.prim_count - k);
     }
     BvhLayout TL = layout_bvh(s->top_nodes, s->n_top_prims ? s->n_top_nodes : 0, 0, true, nodes, big, M.n_node_records);
+    // one stack per ray holds the top-level entries, the sentinel and the mesh level (rt_traverse.h)
+    const uint32_t stack_need = stack_need_of_depth(bvh_depth(s->top_nodes, s->n_top_prims ? s->n_top_nodes : 0)) + 1u + sc->mesh_stack_need + 2u;
+    if (stack_need > RT_STACK_CAP_LIMIT)
+        return fail(RT_ERR_UNSUPPORTED, "BVH too deep: a ray could need %u traversal stack entries (limit %d)", stack_need, RT_STACK_CAP_LIMIT);
+    sc->stack_cap = sc->stack_cap_override ? sc->stack_cap_override : std::max<uint32_t>(RT_STACK_MIN_CAP, stack_need);
     if ((uint64_t)M.n_node_records + nodes.size() >= 0x7FFFFFF0u || top.size() >= RT_LEAF_MAX_FIRST)
         return fail(RT_ERR_UNSUPPORTED, "scene too large for the link encoding (2^26 leaf prims)");
     std::sort(big.begin(), big.end(), [](const DBigLeaf& a, const DBigLeaf& b) { return a.first < b.first; });
@@ -649,6 +698,7 @@ int build_top_level(rt_scene* sc, const rt_scene_desc* s) {
     D.nodes = (const DNode4*)sc->b_nodes.p;
     D.big_leaves = (const DBigLeaf*)sc->b_big.p;
     D.n_big_leaves = (uint32_t)big.size();
+    D.stack_cap = sc->stack_cap;
     D.donate_ok = M.donate_ok ? 1u : 0u;
     if (getenv("RT_NO_DONATE")) D.donate_ok = 0u;      // diagnostic: every ray is traced by its owner alone
     D.objects = (const DObject*)sc->b_objects.p;
@@ -744,6 +794,32 @@ struct Timer {
     }
 };
 
+// Control::overflow as left by the kernels of a render -> status.  Bits 1 / 2 (record / shadow pool) are handled by
+// the chunk loop where child rays exist; seen here they mean the pools were too small for what was asked.
+int ctl_status(uint32_t ov, uint32_t stack_cap) {
+    if (ov & 8u) return fail(RT_ERR_HIP, "internal: a traced ray reached the wrong lane (rt_ordered.h)");
+    if (ov & 32u) return fail(RT_ERR_HIP, "internal: a wave exceeded its round bound (rt_traverse.h)");
+    if (ov & 16u) return fail(RT_ERR_HIP, "internal: a ray waited for its helpers beyond the bound (rt_traverse.h)");
+    if (ov & 4u) return fail(RT_ERR_OVERFLOW, "traversal stack deeper than %u entries", stack_cap);
+    if (ov & 3u) return fail(RT_ERR_OVERFLOW, "ray pool overflow");
+    return RT_OK;
+}
+
+// The Control block of the last render that returned before its kernels had run (rt.h: rt_render_tile_device /
+// _rows_device without stats).  Called by rt_sync and at the start of the next render / update of the scene:
+// waits for that render and reports what it left — once; the frame it wrote is not to be trusted then.
+int check_async(rt_scene* sc) {
+    if (!sc->pending_check) return RT_OK;
+    sc->pending_check = false;
+    HIPCHK(hipEventSynchronize(sc->ev_async));
+    const int rc = ctl_status(sc->h_ctl->overflow, sc->stack_cap);
+    if (rc) {
+        const std::string msg = g_err;
+        return fail(rc, "an earlier asynchronous render of this scene failed: %s", msg.c_str());
+    }
+    return RT_OK;
+}
+
 void to_dcamera(const rt_camera_desc* c, DCamera& d) {
     std::memcpy(d.pos, c->position, 12); std::memcpy(d.u, c->u, 12); std::memcpy(d.v, c->v, 12);
     std::memcpy(d.w, c->w, 12); std::memcpy(d.q, c->q, 12);
@@ -766,6 +842,7 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
     int depth = sc->ds.max_depth;
     if (depth >= RT_MAX_GEN) return fail(RT_ERR_UNSUPPORTED, "MaxRecursionDepth %d exceeds %d", depth, RT_MAX_GEN - 1);
     HIPCHK(hipSetDevice(sc->device));
+    { int arc = check_async(sc); if (arc) return arc; }
     if (depth < 0) {   // ComputeColor returns (0,0,0) for every primary ray (raytracer.cpp:384-386)
         HIPCHK(hipMemset2DAsync(d_rgb, stride, 0, (size_t)w * 3, h, st));
         if (d_hits) HIPCHK(hipMemsetAsync(d_hits, 0xFF, (size_t)w * h * 8, st));
@@ -779,7 +856,7 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
     // per-wave scratch of the trace loops, sized for the largest resident grid of any kernel that runs them
     const size_t max_waves = std::max<size_t>((size_t)std::max(sc->blocks_closest, sc->blocks_shadow) * (RT_TRACE_BLOCK / 64),
                                               (size_t)sc->blocks_ordered * (RT_ORDERED_BLOCK / 64));
-    if ((rc = sc->b_spill.ensure(max_waves * (RT_STACK_MAX - RT_STACK_LDS) * 64 * sizeof(uint2)))) return rc;
+    if ((rc = sc->b_spill.ensure(max_waves * (sc->stack_cap - RT_STACK_LDS) * 64 * sizeof(uint2)))) return rc;
     uint2* spill = (uint2*)sc->b_spill.p;
     // candidate hits of rays whose subtrees were traced by other lanes (rt_traverse.h): 64 x RT_CAND_MAX per wave
     if ((rc = sc->b_cand.ensure(max_waves * 64 * RT_CAND_MAX * sizeof(uint4)))) return rc;
@@ -790,12 +867,8 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
     const bool near = (sc->opt_flags & RT_FLAG_NEAR_FIRST) != 0 || sc->rebuilt;   // non-parity visiting order (rt.h)
     HIPCHK(hipMemsetAsync(ctl, 0, sizeof(Control), st));
 
-    hipEvent_t ev_total_a = nullptr, ev_total_b = nullptr;
-    if (stats) {
-        HIPCHK(hipEventCreate(&ev_total_a));
-        HIPCHK(hipEventCreate(&ev_total_b));
-        HIPCHK(hipEventRecord(ev_total_a, st));
-    }
+    const hipEvent_t ev_total_a = sc->ev_total_a, ev_total_b = sc->ev_total_b;
+    if (stats) HIPCHK(hipEventRecord(ev_total_a, st));
 
     DCamera dc;
     to_dcamera(cam, dc);
@@ -911,7 +984,7 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
             // child rays were spawned: the pools may have overflowed
             HIPCHK(hipMemcpyAsync(sc->h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            if (sc->h_ctl->overflow & 4u) return fail(RT_ERR_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
+            if (sc->h_ctl->overflow & ~3u) return ctl_status(sc->h_ctl->overflow & ~3u, sc->stack_cap);
             if (sc->h_ctl->overflow & 3u) {
                 if (tiles_per_chunk == 1) return fail(RT_ERR_OVERFLOW, "ray pool too small for one 8x8 tile; raise RT_OPT_POOL_RECORDS");
                 tiles_per_chunk = std::max(1u, tiles_per_chunk / 2);
@@ -933,11 +1006,13 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
     if (want_sync) {
         HIPCHK(hipMemcpyAsync(sc->h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if (sc->h_ctl->overflow & 8u) return fail(RT_ERR_HIP, "internal: a traced ray reached the wrong lane (rt_ordered.h)");
-        if (sc->h_ctl->overflow & 32u) return fail(RT_ERR_HIP, "internal: a wave exceeded its round bound (rt_traverse.h)");
-        if (sc->h_ctl->overflow & 16u) return fail(RT_ERR_HIP, "internal: a ray waited for its helpers beyond the bound (rt_traverse.h)");
-        if (sc->h_ctl->overflow & 4u) return fail(RT_ERR_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
-        if (sc->h_ctl->overflow & 3u) return fail(RT_ERR_OVERFLOW, "ray pool overflow");
+        if ((rc = ctl_status(sc->h_ctl->overflow, sc->stack_cap))) return rc;
+    } else {
+        // asynchronous return: what the kernels report (stack / shadow-pool overflow, scheduler bounds) is copied
+        // behind them and looked at by rt_sync or the next call on this scene (check_async) — never dropped
+        HIPCHK(hipMemcpyAsync(sc->h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(sc->ev_async, st));
+        sc->pending_check = true;
     }
 #ifdef RT_TRACE_STATS
     if (want_sync) {
@@ -1003,8 +1078,6 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         stats->records_peak = peak;
         stats->chunks = chunks - retries;     // chunks kept (a chunk that overflowed its pool is redone smaller)
         HIPCHK(hipEventElapsedTime(&stats->ms_total, ev_total_a, ev_total_b));
-        (void)hipEventDestroy(ev_total_a);
-        (void)hipEventDestroy(ev_total_b);
     }
     // fold kernel timings
     float acc[TC_COUNT] = {0};
@@ -1058,13 +1131,14 @@ int rt_upload_scene_ex(int device, const rt_scene_desc* scene, uint32_t upload_f
     if (!out) return fail(RT_ERR_INVALID, "out is NULL");
     if (upload_flags & ~(uint32_t)RT_UPLOAD_REBUILD_MESH_BVH) return fail(RT_ERR_INVALID, "unknown upload flag");
     *out = nullptr;
-    int n = rt_device_count();
-    if (n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
-    if (device < 0 || device >= n) return fail(RT_ERR_NO_DEVICE, "device %d out of range [0,%d)", device, n);
+    // the description is checked first (host work only), so a malformed scene is reported as such on any box
     PhaseClock pc;
     int rc = guarded([&] { return validate_scene(scene); });
     if (rc) return rc;
     pc.lap("validate_scene");
+    int n = rt_device_count();
+    if (n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail(RT_ERR_NO_DEVICE, "device %d out of range [0,%d)", device, n);
     HIPCHK(hipSetDevice(device));
     rt_scene* sc = new (std::nothrow) rt_scene();
     if (!sc) return fail(RT_ERR_OOM, "host allocation failed");
@@ -1073,6 +1147,8 @@ int rt_upload_scene_ex(int device, const rt_scene_desc* scene, uint32_t upload_f
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) sc->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess) { delete sc; return fail(RT_ERR_HIP, "hipStreamCreate failed"); }
     if (hipHostMalloc((void**)&sc->h_ctl, sizeof(Control)) != hipSuccess) { rt_free_scene(sc); return fail(RT_ERR_HIP, "hipHostMalloc failed"); }
+    if (hipEventCreate(&sc->ev_total_a) != hipSuccess || hipEventCreate(&sc->ev_total_b) != hipSuccess ||
+        hipEventCreateWithFlags(&sc->ev_async, hipEventDisableTiming) != hipSuccess) { rt_free_scene(sc); return fail(RT_ERR_HIP, "hipEventCreate failed"); }
     rc = guarded([&] { return build_device_scene(sc, scene, upload_flags); });
     if (rc) { rt_free_scene(sc); return rc; }
     // persistent grids: as many workgroups as are resident at once (RT_TRACE_BLOCKS_PER_CU caps it, for occupancy experiments)
@@ -1100,6 +1176,7 @@ int rt_update_scene(rt_scene* sc, const rt_scene_desc* scene, uint32_t flags) {
         return fail(RT_ERR_INVALID, "rt_update_scene: the mesh arrays differ from the uploaded scene's; upload the scene instead");
     HIPCHK(hipSetDevice(sc->device));
     HIPCHK(hipStreamSynchronize(sc->stream));      // no render of this scene may be in flight (the caller's stream: caller's duty)
+    { int arc = check_async(sc); if (arc) return arc; }
     return guarded([&] { return build_top_level(sc, scene); });
 }
 
@@ -1114,6 +1191,11 @@ int rt_scene_set_option(rt_scene* s, int option, uint64_t value) {
     case RT_OPT_CHUNK_SAMPLES:
         if (value < 64) return fail(RT_ERR_INVALID, "chunk size out of range");
         s->opt_chunk_samples = value;
+        return RT_OK;
+    case RT_OPT_STACK_CAP:
+        if (value != 0 && (value <= RT_STACK_LDS || value > RT_STACK_CAP_LIMIT)) return fail(RT_ERR_INVALID, "stack capacity out of range");
+        s->stack_cap_override = (uint32_t)value;
+        if (value) { s->stack_cap = (uint32_t)value; s->ds.stack_cap = s->stack_cap; }
         return RT_OK;
     default: return fail(RT_ERR_INVALID, "unknown option %d", option);
     }
@@ -1188,7 +1270,7 @@ int rt_sync(rt_scene* s) {
     if (!s) return fail(RT_ERR_INVALID, "scene is NULL");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
-    return RT_OK;
+    return check_async(s);      // (also waits for a render that was enqueued on a caller's stream)
 }
 
 void rt_free_scene(rt_scene* s) {
@@ -1201,6 +1283,7 @@ void rt_free_scene(rt_scene* s) {
         b->release();
     for (auto& e : s->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (hipEvent_t e : {s->ev_total_a, s->ev_total_b, s->ev_async}) if (e) (void)hipEventDestroy(e);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     if (s->h_stage) (void)hipHostFree(s->h_stage);
     if (s->stream) (void)hipStreamDestroy(s->stream);

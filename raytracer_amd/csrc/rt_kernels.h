@@ -294,7 +294,7 @@ struct TraceLds {
     uint8_t  cancel[THREADS];
 };
 template <int THREADS>
-__device__ __forceinline__ TraceStack make_stack(TraceLds<THREADS>& L, uint2* spill, uint4* cand, const WaveWork& ww) {
+__device__ __forceinline__ TraceStack make_stack(TraceLds<THREADS>& L, uint2* spill, uint4* cand, const WaveWork& ww, uint32_t stack_cap) {
     // zero the workgroup-wide words once (all threads of the block call this together at kernel start)
     for (uint32_t i = threadIdx.x; i < (THREADS / 64) * RT_BOARD_PER_WAVE * 16; i += THREADS) L.board[i] = 0;
     L.cand_cnt[threadIdx.x] = 0;
@@ -315,7 +315,8 @@ __device__ __forceinline__ TraceStack make_stack(TraceLds<THREADS>& L, uint2* sp
     st.slot = threadIdx.x;
     st.cand = cand + (size_t)blockIdx.x * THREADS * RT_CAND_MAX;
     size_t wave_slot = (size_t)blockIdx.x * (THREADS / 64) + ww.wave;
-    st.spill = spill + wave_slot * (size_t)((RT_STACK_MAX - RT_STACK_LDS) * 64);
+    st.cap = stack_cap;
+    st.spill = spill + wave_slot * (size_t)((stack_cap - RT_STACK_LDS) * 64);
     st.lane = ww.lane;
     st.sp = 0;
     st.overflow = 0;
@@ -406,7 +407,7 @@ template <bool NEAR>
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_closest(DScene S, Pool P, Control* ctl, int gen, uint2* spill, uint4* cand) {
     __shared__ TraceLds<RT_TRACE_BLOCK> s_lds;
     WaveWork ww;
-    TraceStack st = make_stack(s_lds, spill, cand, ww);
+    TraceStack st = make_stack(s_lds, spill, cand, ww, S.stack_cap);
     const uint32_t begin = ctl->gstart[gen], end = ctl->gstart[gen + 1];
 #ifdef RT_TRACE_STATS
     TraceStatsAcc acc = {};
@@ -461,7 +462,7 @@ struct ShadowIO {
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_shadow(DScene S, Pool P, Control* ctl, int gen, uint2* spill, uint4* cand) {
     __shared__ TraceLds<RT_TRACE_BLOCK> s_lds;
     WaveWork ww;
-    TraceStack st = make_stack(s_lds, spill, cand, ww);
+    TraceStack st = make_stack(s_lds, spill, cand, ww, S.stack_cap);
     const uint32_t begin = ctl->sstart[gen], end = ctl->sstart[gen + 1];
 #ifdef RT_TRACE_STATS
     TraceStatsAcc acc = {};
@@ -504,7 +505,7 @@ template <bool NEAR>
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_mixed(DScene S, Pool P, Control* ctl, int gen_shadow, int gen_closest, uint2* spill, uint4* cand) {
     __shared__ TraceLds<RT_TRACE_BLOCK> s_lds;
     WaveWork ww;
-    TraceStack st = make_stack(s_lds, spill, cand, ww);
+    TraceStack st = make_stack(s_lds, spill, cand, ww, S.stack_cap);
 #ifdef RT_TRACE_STATS
     TraceStatsAcc acc = {};
     st.acc = &acc;

@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
     __shared__ TraceLds<RT_ORDERED_BLOCK> s_lds;
     uint32_t* s_cursor = s_lds.cursor;
     WaveWork ww;
-    TraceStack st = make_stack(s_lds, spill, cand, ww);
+    TraceStack st = make_stack(s_lds, spill, cand, ww, S.stack_cap);
 #ifdef RT_TRACE_STATS
     TraceStatsAcc acc = {};
     st.acc = &acc;

@@ -117,16 +117,22 @@
 #ifndef RT_CAND_MAX
 #define RT_CAND_MAX 16           // candidate hits a ray can collect from donated subtrees before it falls back to tracing alone
 #endif
-#define RT_STACK_MAX 64          // the reference's stack[64] (raytracer.cpp:533,766)
+// Stack entries per ray (LDS part + global spill part): at least the reference's stack[64] (raytracer.cpp:533,766),
+// more when the scene's BVH depths ask for it — one stack holds the top-level entries, a sentinel and the mesh
+// level, and a node record leaves up to three siblings per two reference levels, so a BVH the reference walks
+// with depth + 1 <= 64 entries can need up to ~200 here.  DScene::stack_cap, computed at upload (rt_hip.hip).
+#define RT_STACK_MIN_CAP 64
+#define RT_STACK_CAP_LIMIT 4096
 #ifndef RT_TRACE_BLOCK
 #define RT_TRACE_BLOCK 1024      // threads per workgroup of the trace kernels: one workgroup per CU, its 16 waves share the task board
 #endif
 #define RT_ORDERED_BLOCK 256     // rt_ordered.h: 256 VGPRs per lane, 2 waves per SIMD
 #define RT_BOARD_PER_WAVE 4      // task-board slots per wave of a workgroup (16 words each)
 #ifndef RT_ROUND_CAP
-#define RT_ROUND_CAP (1u << 26)   // rounds of one wave in one kernel; a healthy frame needs tens
+#define RT_ROUND_CAP (1u << 22)   // WORKING rounds of one wave in one trace call (rounds a finished wave spends lingering do not
+                                  // count); a 64 M-sample chunk needs ~2e5, so a stuck wave reports within seconds, not minutes
 #endif
-#define RT_WAIT_ROUNDS_MAX 4000000u   // an owner never waits longer for its helpers (error 16 instead of a hang)
+#define RT_WAIT_ROUNDS_MAX 1000000u   // an owner never waits longer for its helpers (error 16 instead of a hang)
 #ifndef RT_LINGER_SPINS
 #define RT_LINGER_SPINS 20000    // rounds a finished wave keeps looking at the board while others of its workgroup work
 #endif
@@ -169,7 +175,7 @@ typedef f4a f4u __attribute__((aligned(4)));   // 4 floats at dword alignment: o
 
 struct TraceStack {
     uint2*    lds;        // [RT_STACK_LDS][64] for this wave: (link, bits of tEnter)
-    uint2*    spill;      // [(RT_STACK_MAX-RT_STACK_LDS)][64] for this wave (global)
+    uint2*    spill;      // [(cap-RT_STACK_LDS)][64] for this wave (global)
     uint2*    q;          // [RT_LEAF_QUEUE][64] postponed mesh leaves, in visiting order: (link, bits of tEnter)
     // workgroup-wide (LDS unless noted), indexed by the owner's slot = wave * 64 + lane:
     uint32_t* cand_cnt;   // [threads] candidates collected for the ray of that slot
@@ -182,6 +188,7 @@ struct TraceStack {
     uint32_t  slot;       // this lane's slot in the workgroup
     uint32_t  lane;
     uint32_t  sp;
+    uint32_t  cap;        // DScene::stack_cap
     uint32_t  overflow;
 #ifdef RT_TRACE_STATS
     TraceStatsAcc* acc;
@@ -190,10 +197,10 @@ struct TraceStack {
     __device__ __forceinline__ void push(uint32_t link, float t) {
         if (sp < RT_STACK_LDS) {
             lds[sp * 64 + lane] = make_uint2(link, __float_as_uint(t));
-        } else if (sp < RT_STACK_MAX) {
+        } else if (sp < cap) {
             spill[(sp - RT_STACK_LDS) * 64 + lane] = make_uint2(link, __float_as_uint(t));
         } else {
-            overflow = 1;   // the reference's fixed array would overflow here as well
+            overflow = 1;   // cannot happen for a scene that passed the upload (cap covers its BVH depths); reported, not ignored
             return;
         }
         sp++;
@@ -422,6 +429,8 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     uint32_t* rec = st.board + ((start + k) % st.n_board) * 16u;
                     // (rec[15]: closest-hit or any-hit subtree — in rt_ordered.h the waves of a workgroup run both kinds of loop)
                     if (rec[0] == 2u && (MIXED || rec[15] == (ANY_ONLY ? 1u : 0u)) && atomicCAS(&rec[0], 2u, 3u) == 2u) {
+                        // pairs with the poster's release fence: the record's words are read after the claim, not before
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         if (MIXED) lane_any = rec[15] != 0u;
                         home = rec[1];
                         cur = rec[2];
@@ -529,6 +538,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 break;
             }
             __builtin_amdgcn_s_sleep(32);
+            round--;                                 // lingering is not work: RT_ROUND_CAP bounds working rounds
             continue;
         }
         if (any_alive && !was_busy) {

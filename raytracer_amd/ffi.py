@@ -16,7 +16,7 @@ RT_FLAG_SEPARATE_LAUNCHES = 2
 RT_FLAG_NEAR_FIRST = 4        # non-parity visiting order, see include/rt.h
 RT_UPLOAD_REBUILD_MESH_BVH = 1
 RT_UPDATE_VERIFY_MESHES = 1
-RT_OPT_FLAGS, RT_OPT_POOL_RECORDS, RT_OPT_CHUNK_SAMPLES = 1, 2, 3
+RT_OPT_FLAGS, RT_OPT_POOL_RECORDS, RT_OPT_CHUNK_SAMPLES, RT_OPT_STACK_CAP = 1, 2, 3, 4
 
 
 class RtError(RuntimeError):
@@ -56,6 +56,40 @@ class Stats(C.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class BvhNode(C.Structure):
+    """rt_bvh_node (include/rt.h)"""
+    _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("left_or_first", C.c_int32), ("prim_count", C.c_int32)]
+
+
+class MeshBvh(C.Structure):
+    """rt_mesh_bvh (include/rt.h)"""
+    _fields_ = [("node_offset", C.c_uint32), ("node_count", C.c_uint32), ("prim_offset", C.c_uint32),
+                ("prim_count", C.c_uint32), ("face_offset", C.c_uint32), ("face_count", C.c_uint32)]
+
+
+class SceneDesc(C.Structure):
+    """rt_scene_desc (include/rt.h): a view of the pointers + counts, for tests that inspect or alter a scene."""
+    _fields_ = [
+        ("background_color", C.c_float * 3), ("ambient_light", C.c_float * 3), ("shadow_ray_epsilon", C.c_float),
+        ("max_recursion_depth", C.c_int32),
+        ("top_nodes", C.POINTER(BvhNode)), ("n_top_nodes", C.c_uint32),
+        ("top_prim_idx", C.POINTER(C.c_uint32)), ("n_top_prims", C.c_uint32),
+        ("top_prims", C.c_void_p),
+        ("mesh_bvhs", C.POINTER(MeshBvh)), ("n_mesh_bvhs", C.c_uint32),
+        ("mesh_nodes", C.POINTER(BvhNode)), ("n_mesh_nodes", C.c_uint32),
+        ("mesh_prim_face", C.POINTER(C.c_uint32)), ("n_mesh_prims", C.c_uint32),
+        ("faces", C.c_void_p), ("n_faces", C.c_uint32),
+        ("vertex_data", C.c_void_p), ("n_vertices", C.c_uint32),
+        ("meshes", C.c_void_p), ("n_meshes", C.c_uint32),
+        ("triangles", C.c_void_p), ("n_triangles", C.c_uint32),
+        ("spheres", C.c_void_p), ("n_spheres", C.c_uint32),
+        ("planes", C.c_void_p), ("n_planes", C.c_uint32),
+        ("materials", C.c_void_p), ("n_materials", C.c_uint32),
+        ("point_lights", C.c_void_p), ("n_point_lights", C.c_uint32),
+        ("area_lights", C.c_void_p), ("n_area_lights", C.c_uint32),
+    ]
 
 
 def _f3(v):

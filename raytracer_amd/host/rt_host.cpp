@@ -187,11 +187,18 @@ struct rth_builder {
     std::unordered_set<int> touched_set;
 };
 
+// include/rt_host.h: nothing throws across the C boundary (ctypes callers would abort): host allocation failures
+// and any other exception become a NULL / negative return with a message
+#define RTH_GUARD_BEGIN try {
+#define RTH_GUARD_END(ret) } catch (const std::bad_alloc&) { g_err = "host allocation failed"; return ret; } \
+    catch (const std::exception& e_) { g_err = std::string("internal error: ") + e_.what(); return ret; } catch (...) { g_err = "internal error"; return ret; }
+
 extern "C" {
 
 const char* rth_last_error(void) { return g_err.c_str(); }
 
 rth_scene* rth_scene_load(const char* path) {
+    RTH_GUARD_BEGIN
     rth_scene* s = new rth_scene();
     if (!s->st.load(path)) {
         g_err = std::string("cannot load scene blob ") + (path ? path : "(null)");
@@ -199,10 +206,13 @@ rth_scene* rth_scene_load(const char* path) {
         return nullptr;
     }
     return s;
+    RTH_GUARD_END(nullptr)
 }
 int rth_scene_save(const rth_scene* s, const char* path) {
+    RTH_GUARD_BEGIN
     if (!s || !s->st.save(path)) { g_err = "cannot write scene blob"; return RT_ERR_IO; }
     return RT_OK;
+    RTH_GUARD_END(RT_ERR_IO)
 }
 const rt_scene_desc* rth_scene_desc(const rth_scene* s) { return s ? &s->st.desc : nullptr; }
 int rth_scene_num_cameras(const rth_scene* s) { return s ? (int)s->st.cameras.size() : 0; }
@@ -234,7 +244,7 @@ int rth_scene_set_max_depth(rth_scene* s, int d) {
 void rth_scene_free(rth_scene* s) { delete s; }
 
 // ------------------------------------------------------------------ builder
-rth_builder* rth_builder_new(void) { return new rth_builder(); }
+rth_builder* rth_builder_new(void) { RTH_GUARD_BEGIN return new rth_builder(); RTH_GUARD_END(nullptr) }
 void rth_builder_free(rth_builder* b) { delete b; }
 
 void rth_builder_set_globals(rth_builder* b, const float bg[3], const float amb[3], float eps, int depth) {
@@ -244,6 +254,7 @@ void rth_builder_set_globals(rth_builder* b, const float bg[3], const float amb[
     b->st.max_recursion_depth = depth;
 }
 int rth_builder_add_vertices(rth_builder* b, const float* xyz, int n) {
+    RTH_GUARD_BEGIN
     int first = (int)b->st.vertex_data.size() + 1;
     for (int i = 0; i < n; i++) {
         rt_vertex v{};
@@ -251,10 +262,13 @@ int rth_builder_add_vertices(rth_builder* b, const float* xyz, int n) {
         b->st.vertex_data.push_back(v);
     }
     return first;
+    RTH_GUARD_END(RT_ERR_OOM)
 }
 int rth_builder_add_material(rth_builder* b, const rt_material* m) {
+    RTH_GUARD_BEGIN
     b->st.materials.push_back(*m);
     return (int)b->st.materials.size();
+    RTH_GUARD_END(RT_ERR_OOM)
 }
 void rth_builder_add_point_light(rth_builder* b, const float pos[3], const float inten[3]) {
     rt_point_light l;
@@ -299,6 +313,7 @@ static void set_transform(uint32_t& flags, float M[16], float Minv[16], float mb
 
 int rth_builder_add_mesh(rth_builder* b, const int32_t* faces, int n_faces, int material_id, int smooth,
                          const float* transform, const float* motion_blur) {
+    RTH_GUARD_BEGIN
     const int nv = (int)b->st.vertex_data.size();
     rth_builder::MeshExtra ex;
     ex.is_instance = false;
@@ -330,10 +345,12 @@ int rth_builder_add_mesh(rth_builder* b, const int32_t* faces, int n_faces, int 
     b->st.meshes.push_back(m);
     b->mesh_extra.push_back(std::move(ex));
     return (int)b->st.meshes.size() - 1;
+    RTH_GUARD_END(RT_ERR_OOM)
 }
 
 int rth_builder_add_instance(rth_builder* b, int base, int material_id, const float* transform, int reset,
                              const float* motion_blur) {
+    RTH_GUARD_BEGIN
     if (base < 0 || base >= (int)b->st.meshes.size()) { g_err = "bad base mesh"; return RT_ERR_INVALID; }
     int orig = base;
     while (b->mesh_extra[orig].is_instance) orig = b->mesh_extra[orig].original;   // parser.cpp:694-698
@@ -354,10 +371,12 @@ int rth_builder_add_instance(rth_builder* b, int base, int material_id, const fl
     b->st.meshes.push_back(m);
     b->mesh_extra.push_back(std::move(ex));
     return (int)b->st.meshes.size() - 1;
+    RTH_GUARD_END(RT_ERR_OOM)
 }
 
 int rth_builder_add_triangle(rth_builder* b, int i0, int i1, int i2, int material_id, const float* transform,
                              const float* motion_blur) {
+    RTH_GUARD_BEGIN
     const int nv = (int)b->st.vertex_data.size();
     if (i0 < 1 || i1 < 1 || i2 < 1 || i0 > nv || i1 > nv || i2 > nv) { g_err = "triangle index out of range"; return RT_ERR_INVALID; }
     rt_triangle t{};
@@ -372,10 +391,12 @@ int rth_builder_add_triangle(rth_builder* b, int i0, int i1, int i2, int materia
     b->tri_world.push_back(transform ? transform_box(local, t.transform) : local);
     b->st.triangles.push_back(t);
     return (int)b->st.triangles.size() - 1;
+    RTH_GUARD_END(RT_ERR_OOM)
 }
 
 int rth_builder_add_sphere(rth_builder* b, int center_id, float radius, int material_id, const float* transform,
                            const float* motion_blur) {
+    RTH_GUARD_BEGIN
     if (center_id < 1 || center_id > (int)b->st.vertex_data.size()) { g_err = "sphere centre out of range"; return RT_ERR_INVALID; }
     rt_sphere s{};
     s.material_id = material_id;
@@ -390,9 +411,11 @@ int rth_builder_add_sphere(rth_builder* b, int center_id, float radius, int mate
     b->sph_world.push_back(transform ? transform_box(local, s.transform) : local);
     b->st.spheres.push_back(s);
     return (int)b->st.spheres.size() - 1;
+    RTH_GUARD_END(RT_ERR_OOM)
 }
 
 int rth_builder_add_plane(rth_builder* b, int point_id, const float normal[3], int material_id) {
+    RTH_GUARD_BEGIN
     if (point_id < 1 || point_id > (int)b->st.vertex_data.size()) { g_err = "plane point out of range"; return RT_ERR_INVALID; }
     rt_plane p{};
     p.material_id = material_id;
@@ -401,11 +424,13 @@ int rth_builder_add_plane(rth_builder* b, int point_id, const float normal[3], i
     p.plane_d = -(dot(n, ld(b->st.vertex_data[point_id - 1].pos)));
     b->st.planes.push_back(p);
     return (int)b->st.planes.size() - 1;
+    RTH_GUARD_END(RT_ERR_OOM)
 }
 
 int rth_builder_add_camera_lookat(rth_builder* b, const float position[3], const float gaze_point[3], const float up[3],
                                   float fovy_deg, float near_distance, int width, int height, int num_samples,
                                   float aperture_size, float focus_distance, const char* name) {
+    RTH_GUARD_BEGIN
     // parser.cpp:343-446 (lookAt branch, no camera Transformations)
     V3 pos = ld(position);
     V3 gaze = ld(gaze_point) - pos;
@@ -436,9 +461,11 @@ int rth_builder_add_camera_lookat(rth_builder* b, const float position[3], const
     b->st.cameras.push_back(c);
     b->st.camera_names.push_back(name ? name : "out.png");
     return (int)b->st.cameras.size() - 1;
+    RTH_GUARD_END(RT_ERR_OOM)
 }
 
 rth_scene* rth_builder_finish(rth_builder* b) {
+    RTH_GUARD_BEGIN
     rth_scene* out = new rth_scene();
     RtSceneStore& s = out->st;
     s = b->st;
@@ -496,6 +523,7 @@ rth_scene* rth_builder_finish(rth_builder* b) {
     else { s.top_nodes.clear(); s.top_prim_idx.clear(); }
     s.finalize();
     return out;
+    RTH_GUARD_END(nullptr)
 }
 
 void rth_mat_translation(float out[16], float x, float y, float z) { mat_identity(out); out[3] = x; out[7] = y; out[11] = z; }

@@ -68,10 +68,16 @@ struct RtSceneStore {
         if (fwrite(&n, 8, 1, f) != 1) return false;
         return n == 0 || fwrite(v.data(), sizeof(T), n, f) == n;
     }
+    // A count comes from the file: it is believed only as far as the file has bytes left for it (a damaged or
+    // hostile blob must not make the loader allocate gigabytes).
     template <class T> static bool rd(FILE* f, std::vector<T>& v) {
         uint64_t n = 0;
         if (fread(&n, 8, 1, f) != 1) return false;
-        if (n > (1ull << 33) / sizeof(T)) return false;
+        const long here = ftell(f);
+        if (here < 0 || fseek(f, 0, SEEK_END) != 0) return false;
+        const long end = ftell(f);
+        if (end < here || fseek(f, here, SEEK_SET) != 0) return false;
+        if (n > (uint64_t)(end - here) / sizeof(T)) return false;
         v.resize(n);
         return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
     }
@@ -126,6 +132,9 @@ struct RtSceneStore {
             camera_names.emplace_back(c.begin(), c.end());
         }
         fclose(f);
+        // arrays that are indexed by one another's counts must agree (n_top_prims is the length of both top-level
+        // arrays, include/rt.h); a camera without a name has no output file
+        ok = ok && top_prim_idx.size() == top_prims.size() && cameras.size() == camera_names.size();
         if (ok) finalize();
         return ok;
     }

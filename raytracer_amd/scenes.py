@@ -396,3 +396,28 @@ def glossy_area_scene(grid=48, width=320, height=200, num_samples=4, name=None):
     s.camera = dict(position=(0.3, 1.4, 6.5), gaze_point=(0, -0.1, 0), up=(0, 1, 0), fovy=34.0, near=1.0, width=width,
                     height=height, num_samples=num_samples)
     return s
+
+
+def deep_chain_scene(n=64, width=160, height=120, name="deep_chain"):
+    """A mesh whose midpoint-split BVH (raytracer.cpp:296-339) is a CHAIN about n levels deep: n self-similar
+    triangles at x_k = 2^20 * 0.4^k facing the camera at the origin, each split peels off the largest one.  Every
+    ray inside the cone walks the whole chain, left (= small, near) child first, with one pending sibling per level
+    — 60-odd entries of the reference's stack[64], and ~3 per two levels of the device's one stack (rt_traverse.h),
+    which is what the per-scene stack capacity exists for.  A rotated, scaled instance of the chain and a point
+    light add transformed and any-hit walks of the same tree."""
+    s = SynthScene(name)
+    s.max_depth = 2
+    s.background = (12, 24, 48)
+    s.ambient = (30, 30, 30)
+    x = (2.0 ** 20) * 0.4 ** np.arange(n, dtype=np.float64)
+    v = np.stack([np.stack([x, -0.4 * x, -0.4 * x], -1), np.stack([x, 0.4 * x, -0.4 * x], -1), np.stack([x, 0 * x, 0.4 * x], -1)], 1)
+    verts = v.reshape(-1, 3).astype(np.float32)
+    faces = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    s.vertices = [(0, 0, 0)]
+    s.materials = [dict(ambient=(1, 1, 1), diffuse=(0.8, 0.5, 0.3), specular=(0.5, 0.5, 0.5), phong=10.0),
+                   dict(type=ffi.RT_MAT_MIRROR, ambient=(0.2, 0.2, 0.2), diffuse=(0.2, 0.3, 0.2), specular=(0.5, 0.5, 0.5), mirror=(0.6, 0.6, 0.6), phong=30.0)]
+    s.point_lights = [((-3.0, 1.0, 2.0), (900, 800, 700))]
+    s.meshes = [dict(verts=verts, faces=faces, material=1)]
+    s.instances = [dict(base=0, material=2, transform=[("s", (0.5, 0.7, 0.7)), ("r", (35.0, 0, 0, 1)), ("t", (0.0, 0.0, 0.0))], reset=False)]
+    s.camera = dict(position=(0.0, 0.0, 0.0), gaze_point=(1.0, 0.25, 0.0), up=(0, 0, 1), fovy=70.0, near=1.0, width=width, height=height, num_samples=1)
+    return s

@@ -8,9 +8,17 @@ sys.path.insert(0, ROOT)
 from raytracer_amd import scenes
 from oracle import binding as ob
 
-out = {}
-for name, sc in [("mesh1m_1920x1080", scenes.mesh_scene(709, 1920, 1080)),
-                 ("inst10_1920x1080", scenes.instanced_scene(709, 1920, 1080))]:
+# usage: workload_bytes.py [workload names...]   (no names = all; entries of other workloads are kept)
+path = os.path.join(ROOT, "profiles", "workload_bytes.json")
+out = json.load(open(path)) if os.path.exists(path) else {}
+WORKLOADS = [("mesh1m_1920x1080", lambda: scenes.mesh_scene(709, 1920, 1080)),
+             ("inst10_1920x1080", lambda: scenes.instanced_scene(709, 1920, 1080)),
+             # BASELINE configs[4] / SURVEY 8d-M5: the frame bench.py --gpus N splits over N GPUs
+             ("inst10_7680x4320", lambda: scenes.instanced_scene(709, 7680, 4320))]
+for name, make in WORKLOADS:
+    if sys.argv[1:] and name not in sys.argv[1:]:
+        continue
+    sc = make()
     hs = sc.build()
     cam = hs.camera(0)
     t = time.time()
@@ -26,5 +34,5 @@ for name, sc in [("mesh1m_1920x1080", scenes.mesh_scene(709, 1920, 1080)),
         "formula": "32*(N_top+N_mesh) + 36*T_tri + 16*T_sph + 16*T_pln + 96*E_inst + 48 per ray (SURVEY.md 8d)",
     }
     print(name, json.dumps(out[name]), flush=True)
-with open(os.path.join(ROOT, "profiles", "workload_bytes.json"), "w") as f:
+with open(path, "w") as f:
     json.dump(out, f, indent=1)

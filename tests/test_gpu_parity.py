@@ -12,6 +12,9 @@ pytestmark = pytest.mark.gpu
 
 GOLD = ["hw1_simple", "hw1_spheres_mirror", "hw1_cornellbox_recursive", "hw1_two_spheres", "hw1_spheres_with_plane",
         "hw2_mirror_room", "hw2_metal_glass_plates", "hw2_two_berserkers", "hw2_ellipsoids", "hw2_simple_transform",
+        # the scanned 100 000-face mesh (deep midpoint tree) and a tile of the scene whose top-level
+        # BVH is a single 13-prim leaf (every ray enters every instance whose box it touches)
+        "hw2_davids_camera_000", "hw2_grass_desert",
         "hw3_spheres_dof", "hw3_cornellbox_boxes_dynamic",
         # shading draws random numbers (area light / Roughness > 0): the depth-first pixel loop of rt_ordered.h
         "hw3_cornellbox_area", "hw3_cornellbox_brushed_metal", "hw3_metal_glass_plates",
@@ -37,7 +40,9 @@ def test_golden_reference_scene(rt, name):
     rgb, hits = ds.render(cam, *tile, want_hits=True)
     ds.close()
     st = util.image_stats(rgb, util.golden_image(name))
-    ok = util.hit_ids_match(hits, util.golden_hits(name))
+    # the primitive id of the north_star: (kind, object) AND, for meshes, the triangle — the faceIdx this library
+    # reports, joined to its vertex ids, must be the face the reference's IntersectTopBVH returned (raytracer.cpp:527-531)
+    ok = util.hit_ids_match(hits, util.golden_hits(name), hs)
     assert ok.mean() >= 0.9999, f"hit-id parity {ok.mean()}"
     assert st["within1"] >= 0.999, st
     assert ok.all() and st["exact"] == 1.0, (st, float(ok.mean()))   # the bar this build holds itself to
@@ -170,6 +175,130 @@ def test_full_size_properties_mesh1m(rt):
     assert (win == a[y0:y0 + h, x0:x0 + w]).all() and (hw == ha[y0:y0 + h, x0:x0 + w]).all()
     o_rgb, o_hits, _ = ob.render(hs, cam, x0=x0, y0=y0, w=w, h=h, want_hits=True)
     assert (win == o_rgb).all() and (hw == o_hits).all()
+
+
+@pytest.fixture(scope="module")
+def inst10_full(rt):
+    """The 10-instance, 10 M-triangle scene of BASELINE configs[2..4], built once for the full-size tests."""
+    return rt.scenes.instanced_scene(709, 7680, 4320).build()
+
+
+def test_full_size_properties_inst10_8k_config4(rt, inst10_full):
+    """BASELINE configs[4] at its real size: the 7680x4320 frame of the 10 M-triangle instanced scene, depth 6.
+    (a) the whole frame in one call: ray-count identities; (b) a 1024-row band rendered as the 8 interleaved
+    row parts of an 8-GPU node, one after the other on this GPU, stitches to the same band rendered in one call,
+    byte for byte and id for id, and the parts' ray counts add up to the band's; (c) a window of the band equals
+    the oracle's."""
+    import torch
+    from oracle import binding as ob
+    hs = inst10_full
+    hs.set_camera_resolution(0, 7680, 4320, 1)
+    cam = hs.camera(0)
+    W, H = 7680, 4320
+    ds = rt.DeviceScene(hs, 0)
+    dev = "cuda:0"
+    fb = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+    st = rt.Stats()
+    ds.render_device(cam, 0, 0, W, H, fb.data_ptr(), W * 3, stats=st)
+    assert st.rays_primary == W * H and st.chunks == 1
+    assert st.rays_secondary > 0 and st.rays_shadow > st.rays_primary          # depth 6: children, two lights per lit hit
+    y0, bh = 1664, 1024                                                          # a band through the instances
+    band = torch.zeros((bh, W, 3), dtype=torch.uint8, device=dev)
+    hits = torch.zeros((bh, W, 2), dtype=torch.int32, device=dev)
+    sb = rt.Stats()
+    ds.render_device(cam, 0, y0, W, bh, band.data_ptr(), W * 3, d_hits_ptr=hits.data_ptr(), stats=sb)
+    assert torch.equal(band, fb[y0:y0 + bh])                                     # a tile does not depend on the rest of the frame
+    merged = torch.full((bh, W, 3), 7, dtype=torch.uint8, device=dev)
+    mhits = torch.full((bh, W, 2), 7, dtype=torch.int32, device=dev)
+    tot = [0, 0, 0]
+    for p in range(8):
+        part = torch.full((bh, W, 3), 9, dtype=torch.uint8, device=dev)
+        phits = torch.full((bh, W, 2), 9, dtype=torch.int32, device=dev)
+        sp = rt.Stats()
+        ds.render_rows_device(cam, 0, y0, W, bh, 8, p, part.data_ptr(), W * 3, d_hits_ptr=phits.data_ptr(), stats=sp)
+        rows = rt.multigpu.rows_of(p, 8, bh).to(dev)
+        merged[rows] = part[rows]
+        mhits[rows] = phits[rows]
+        tot = [tot[0] + sp.rays_primary, tot[1] + sp.rays_secondary, tot[2] + sp.rays_shadow]
+    assert torch.equal(merged, band) and torch.equal(mhits, hits)
+    assert tot == [sb.rays_primary, sb.rays_secondary, sb.rays_shadow] and sb.rays_primary == W * bh
+    ds.close()
+    x0, wy, ww, wh = 3712, y0 + 448, 256, 160
+    o_rgb, o_hits, _ = ob.render(hs, cam, x0=x0, y0=wy, w=ww, h=wh, want_hits=True)
+    assert (band[wy - y0:wy - y0 + wh, x0:x0 + ww].cpu().numpy() == o_rgb).all()
+    assert (hits[wy - y0:wy - y0 + wh, x0:x0 + ww].cpu().numpy().view(np.uint32) == o_hits).all()
+    assert (o_hits[..., 0] != 0xFFFFFFFF).mean() > 0.3                            # the window looks at geometry
+
+
+def test_full_size_properties_inst10_4k_64spp_config3(rt, inst10_full):
+    """BASELINE configs[3] at its real size: 3840x2160 at 64 spp, depth 6, on a 512-row band — 125.8 M primary
+    samples, more than one chunk of the default 64 M, so the multi-chunk MT19937 scratch and a 27 GB record pool
+    are what runs.  The band must not depend on how it is chunked (a second render with 16 M-sample chunks), the
+    primary-ray count is samples x pixels, and a window of it equals the oracle's (bytes and ids)."""
+    import torch
+    from oracle import binding as ob
+    hs = inst10_full
+    hs.set_camera_resolution(0, 3840, 2160, 64)
+    cam = hs.camera(0)
+    assert cam.num_samples == 64 and cam.samples_per_side == 8
+    W, y0, bh = 3840, 824, 512
+    dev = "cuda:0"
+    ds = rt.DeviceScene(hs, 0)
+    a = torch.zeros((bh, W, 3), dtype=torch.uint8, device=dev)
+    ha = torch.zeros((bh, W, 2), dtype=torch.int32, device=dev)
+    sa = rt.Stats()
+    ds.render_device(cam, 0, y0, W, bh, a.data_ptr(), W * 3, d_hits_ptr=ha.data_ptr(), stats=sa)
+    assert sa.chunks > 1 and sa.rays_primary == W * bh * 64
+    ds.set_option(rt.RT_OPT_CHUNK_SAMPLES, 16 << 20)
+    b = torch.zeros_like(a)
+    sb = rt.Stats()
+    ds.render_device(cam, 0, y0, W, bh, b.data_ptr(), W * 3, stats=sb)
+    ds.close()
+    assert sb.chunks >= 7 and torch.equal(a, b)
+    assert [sa.rays_primary, sa.rays_secondary, sa.rays_shadow] == [sb.rays_primary, sb.rays_secondary, sb.rays_shadow]
+    x0, wy, ww, wh = 1856, y0 + 224, 64, 40
+    o_rgb, o_hits, _ = ob.render(hs, cam, x0=x0, y0=wy, w=ww, h=wh, want_hits=True)
+    assert (a[wy - y0:wy - y0 + wh, x0:x0 + ww].cpu().numpy() == o_rgb).all()
+    assert (ha[wy - y0:wy - y0 + wh, x0:x0 + ww].cpu().numpy().view(np.uint32) == o_hits).all()
+    hs.set_camera_resolution(0, 7680, 4320, 1)
+
+
+def test_deep_chain_bvh_vs_oracle(rt):
+    """a mesh BVH the reference walks with 63 of its 64 stack entries (a 62-level chain,
+    scenes.deep_chain_scene) needs ~100 entries of the device's one stack (three pending siblings per two levels, the
+    top level and the sentinel on the same stack); the capacity is derived from the BVH depths at upload.  Image,
+    hit ids and ray counts against the oracle, untransformed and as a transformed mirror instance."""
+    spec = rt.scenes.deep_chain_scene()
+    st = _vs_oracle(rt, spec)
+    assert st.rays_secondary > 0 and st.rays_shadow > 0
+
+
+def test_overflow_in_an_asynchronous_render_is_reported(rt):
+    """rt_render_tile_device without stats returns before its kernels have run; what they detect must not
+    be lost.  With the traversal stack cut to 11 entries (RT_OPT_STACK_CAP, a diagnostic option) the mesh frame
+    overflows: the call itself returns RT_OK, rt_sync returns RT_ERR_OVERFLOW — once — and after the option is
+    lifted the scene renders the correct frame again."""
+    import torch
+    hs = rt.scenes.mesh_scene(grid=128, width=320, height=200).build()
+    cam = hs.camera(0)
+    ds = rt.DeviceScene(hs, 0)
+    good, _ = ds.render(cam)
+    fb = torch.zeros((200, 320, 3), dtype=torch.uint8, device="cuda:0")
+    ds.set_option(rt.RT_OPT_STACK_CAP, 11)
+    ds.render_device(cam, 0, 0, 320, 200, fb.data_ptr(), 320 * 3)                 # asynchronous: no stats, depth 0
+    with pytest.raises(rt.RtError, match="stack"):
+        ds.sync()
+    ds.sync()                                                                      # reported once
+    ds.render_device(cam, 0, 0, 320, 200, fb.data_ptr(), 320 * 3)
+    with pytest.raises(rt.RtError, match="earlier asynchronous render"):
+        ds.render(cam)                                                             # ... or by the next call on the scene
+    ds.set_option(rt.RT_OPT_STACK_CAP, 64)
+    again, _ = ds.render(cam)
+    assert (again == good).all()
+    ds.render_device(cam, 0, 0, 320, 200, fb.data_ptr(), 320 * 3)
+    ds.sync()
+    assert (fb.cpu().numpy() == good).all()
+    ds.close()
 
 
 def test_subtree_donation_is_exact(rt, tmp_path):
@@ -324,7 +453,7 @@ def test_near_first_mode_meets_the_north_star_tolerance_on_reference_scenes(rt, 
     rgb, hits = ds.render(cam, *tile, want_hits=True)
     ds.close()
     st = util.image_stats(rgb, util.golden_image(name))
-    ok = util.hit_ids_match(hits, util.golden_hits(name))
+    ok = util.hit_ids_match(hits, util.golden_hits(name), hs)      # triangles included
     print(f"near-first {name}: hit ids {ok.mean():.6f} exact {st['exact']:.6f} within1 {st['within1']:.6f}")
     assert ok.mean() >= 0.9999, f"hit-id agreement {ok.mean()}"
     assert st["within1"] >= 0.999, st
@@ -370,7 +499,7 @@ def test_rebuilt_mesh_bvh_mode_meets_the_north_star_tolerance_on_reference_scene
     rgb, hits = ds.render(cam, *tile, want_hits=True)
     ds.close()
     st = util.image_stats(rgb, util.golden_image(name))
-    ok = util.hit_ids_match(hits, util.golden_hits(name))
+    ok = util.hit_ids_match(hits, util.golden_hits(name), hs)      # triangles included
     print(f"rebuilt {name}: hit ids {ok.mean():.6f} exact {st['exact']:.6f} within1 {st['within1']:.6f}")
     assert ok.mean() >= 0.9999, f"hit-id agreement {ok.mean()}"
     assert st["within1"] >= 0.999, st

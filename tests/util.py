@@ -42,12 +42,35 @@ def golden_tile(name):
     return tuple(int(v) for v in z["tile"]) if "tile" in z.files else None
 
 
-def hit_ids_match(hits_u32, ref6, scene_faces=None):
-    """Fraction of pixels whose (kind, index) equal the reference's.  hits_u32: [h,w,2] as rt.h documents."""
+def scene_faces(hs):
+    """Faces / mesh tables read back out of the rt_scene_desc: vertex ids per face, face_offset per mesh BVH,
+    mesh BVH per scene.meshes entry."""
+    import ctypes as C
+    from raytracer_amd.ffi import SceneDesc
+    d = SceneDesc.from_address(hs.desc_ptr)
+    faces = np.ctypeslib.as_array((C.c_int32 * (7 * d.n_faces)).from_address(d.faces)).reshape(-1, 7)[:, :3].copy() if d.n_faces else np.zeros((0, 3), np.int32)
+    bv = np.array([[d.mesh_bvhs[b].face_offset] for b in range(d.n_mesh_bvhs)], np.int64).reshape(-1)
+    mesh_words = 3 + 16 + 16 + 3          # rt_mesh: bvh_index, material_id, flags, two matrices, motion blur
+    ms = np.ctypeslib.as_array((C.c_int32 * (mesh_words * d.n_meshes)).from_address(d.meshes)).reshape(-1, mesh_words).copy() if d.n_meshes else np.zeros((0, mesh_words), np.int32)
+    return {"tri": faces, "face_offset": bv, "mesh_bvh": ms[:, 0].astype(np.int64)}
+
+
+def hit_ids_match(hits_u32, ref6, hs=None):
+    """Per pixel: is the primary hit the reference's?  hits_u32: [h,w,2] as rt.h documents (kind<<28 | object
+    index, faceIdx); ref6: the fixture (kind, index, i0, i1, i2, t bits from the reference's IntersectTopBVH,
+    raytracer.cpp:527-531).  (kind, index) must be equal; with `hs` (the scene) a mesh hit's faceIdx is also
+    joined to its vertex ids and must name the triangle (i0, i1, i2) the reference returned."""
     miss = hits_u32[..., 0] == 0xFFFFFFFF
     kind = np.where(miss, -1, (hits_u32[..., 0] >> 28).astype(np.int64))
     index = (hits_u32[..., 0] & 0x0FFFFFFF).astype(np.int64)
     ok = (kind == ref6[..., 0]) & (miss | (index == ref6[..., 1]))
+    if hs is not None:
+        m = ok & (kind == 0)
+        if m.any():
+            f = scene_faces(hs)
+            fi = hits_u32[..., 1][m].astype(np.int64)
+            tri = f["tri"][f["face_offset"][f["mesh_bvh"][index[m]]] + fi]
+            ok[m] = (tri == ref6[..., 2:5][m]).all(axis=-1)
     return ok
 
 
