@@ -201,14 +201,14 @@ def roofline_single(acc, rays, wb, workload_key):
     return r, bytes_closest
 
 
-def roofline_all_traces(acc, rays_rank, wb):
+def roofline_all_traces(acc, rays_rank, wb, steps):
     """Depth > 0: a frame is a chain of trace launches (k_trace_closest for generation 0, then one k_trace_mixed per
     bounce, a last k_trace_shadow): the figure is over all of them on this rank — algorithmic bytes of the rays
     this rank traced over the summed launch time (bytes per launch over the average launch: the same ratio)."""
     n_launch = acc["n_closest"] + acc["n_shadow"]
     dur = (acc["closest"] + acc["shadow"]) * 1e-3
-    steps_bytes = wb["closest_bytes_per_ray"] * (rays_rank[0] + rays_rank[1]) + wb["shadow_bytes_per_ray"] * rays_rank[2]
-    return n_launch, dur, steps_bytes
+    frame_bytes = wb["closest_bytes_per_ray"] * (rays_rank[0] + rays_rank[1]) + wb["shadow_bytes_per_ray"] * rays_rank[2]
+    return n_launch, dur, frame_bytes * steps
 
 
 def main():
@@ -239,6 +239,8 @@ def main():
     rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
     if rehearse:
         e.local_rank = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(150, exit=True)   # a rehearsal that stalls says where
     torch.cuda.set_device(e.local_rank)
     e.dev = torch.device("cuda", e.local_rank)
     if e.world > 1:
@@ -309,7 +311,7 @@ def main():
             rs = Run(e, scenes.instanced_scene(args.grid, strong_w, strong_h))
             k = max(2, min(5, args.steps))
             x = rs.timed(k, 1)
-            n_launch, dur, bts = roofline_all_traces(x["acc"], x["rays_rank"], wb_all["inst10_7680x4320"])
+            n_launch, dur, bts = roofline_all_traces(x["acc"], x["rays_rank"], wb_all["inst10_7680x4320"], k)
             line["strong_scaling_base"] = {
                 "workload": f"inst10: 10 instances of the {2 * (args.grid - 1) ** 2}-triangle mesh, {strong_w}x{strong_h}, 1 spp, depth 6 (BASELINE configs[4])",
                 "value": sum(x["rays_frame"]) / (x["elapsed"] / k) / 1e6, "unit": "Mrays/s", "n_gpus": 1, "steps": k,
@@ -331,7 +333,7 @@ def main():
         rays_per_frame = sum(res["rays_frame"])
         ms_per_step = res["elapsed"] / args.steps * 1e3
         value = rays_per_frame / (res["elapsed"] / args.steps) / 1e6
-        n_launch, dur, bts = roofline_all_traces(res["acc"], res["rays_rank"], wb_all["inst10_7680x4320"])
+        n_launch, dur, bts = roofline_all_traces(res["acc"], res["rays_rank"], wb_all["inst10_7680x4320"], args.steps)
         run.close()
         weak = None
         if not args.no_extras:
