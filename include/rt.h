@@ -329,6 +329,25 @@ int rt_render_tile_device(rt_scene* s, const rt_camera_desc* cam,
                           void* d_rgb_out, size_t rgb_row_stride_bytes,
                           void* d_hit_id_out, rt_stats* stats, void* hip_stream);
 
+/* rt_render_tile_device for callers that cannot allocate: HIP-graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  It has no counterpart in the reference (whose loop allocates nothing but its image,
+ * raytracer.cpp:34).  The call allocates NOTHING — no device or pinned memory, no events: everything a render
+ * otherwise keeps in buffers of the scene (control block, traversal spill stacks and donation candidates, the
+ * ray-record pool and shadow slots of a chunk, the MT19937 state of multi-sample chunks) lives in one 32 MiB
+ * array inside the library's code object, of which every GPU the library runs on holds its own copy until the
+ * process ends.  The trace kernels run on a reduced grid (16 workgroups), so this is the entry point for small
+ * tiles, not for frames.  Limits: tile_w * tile_h * num_samples <= 4 194 304 (RT_ERR_INVALID beyond); scenes
+ * whose shading draws random numbers (area lights, Roughness > 0) are refused (RT_ERR_UNSUPPORTED), as is a
+ * scene whose BVHs are so deep that the spill stacks do not fit.  Output, hit ids and chunking behave as in
+ * rt_render_tile_device (no stats); it returns after enqueueing when the scene spawns no child rays and
+ * synchronises the stream otherwise (a chunk's pool-overflow check), failures of an early return being reported
+ * as there.  All calls on one GPU share that GPU's array, whatever the scene: calls that overlap in time on one
+ * GPU (other streams, other threads, other scenes) race — serialise them. */
+int rt_render_tile_device_noalloc(rt_scene* s, const rt_camera_desc* cam,
+                                  int x0, int y0, int tile_w, int tile_h,
+                                  void* d_rgb_out, size_t rgb_row_stride_bytes,
+                                  void* d_hit_id_out, void* hip_stream);
+
 /* Multi-GPU load balancing: as rt_render_tile_device, but only the 8-pixel-high
  * tile rows ty (counted from the top of the rectangle) with ty % row_parts ==
  * row_part are rendered; all other bytes of the output buffers are left

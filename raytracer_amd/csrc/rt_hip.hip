@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <chrono>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -84,6 +85,21 @@ enum TimeCat { TC_RAYGEN, TC_CLOSEST, TC_SHADE, TC_SHADOW, TC_COMBINE, TC_RESOLV
 
 }  // namespace
 
+// ---- work memory of rt_render_tile_device_noalloc (include/rt.h): one array per GPU, inside the code object, so
+// that the call needs no hipMalloc.  It holds everything a render otherwise keeps in buffers of the scene: the
+// Control block, the traversal spill stacks and donation candidates of a reduced trace grid, the ray-record pool
+// and shadow slots of a chunk, and the MT19937 scratch of multi-sample chunks.  `scratch` itself is only a
+// host-side handle of the symbol: the device address of each GPU's copy is asked for once per device, with that
+// device current (rt_upload_scene_ex), and only that pointer is ever handed to kernels, memsets or copies.
+// Every call on a GPU shares that GPU's array: calls that overlap on one GPU race (rt.h says so).
+#define RT_NOALLOC_SCRATCH_BYTES (32u << 20)
+#define RT_NOALLOC_MAX_SAMPLES (1u << 22)   // tile_w * tile_h * num_samples accepted by the entry point
+#define RT_NOALLOC_BLOCKS 16                // trace workgroups it launches (their spill / candidate areas must fit)
+#define RT_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+static unsigned char* g_scratch_ptr[RT_MAX_DEVICES];   // device address of `scratch` on each GPU (0 = not asked yet)
+static std::mutex g_scratch_mutex;
+
 struct MeshRoot { uint32_t root_link; float rmin[3], rmax[3]; };
 struct rt_scene {
     int device = 0;
@@ -135,6 +151,7 @@ struct rt_scene {
     // deepest traversal stack any ray of this scene can need (entries), from the BVH depths found at upload
     uint32_t mesh_stack_need = 0, stack_cap = RT_STACK_MIN_CAP;
     uint32_t stack_cap_override = 0;   // RT_OPT_STACK_CAP (diagnostic)
+    unsigned char* static_ws = nullptr;   // this GPU's copy of `scratch` (device address)
 };
 
 namespace {
@@ -830,8 +847,10 @@ void to_dcamera(const rt_camera_desc* c, DCamera& d) {
     d.dof = c->has_depth_of_field;
 }
 
+// ws != nullptr: the no-allocation variant — all work memory is carved out of that GPU's static array instead of the
+// scene's buffers, and nothing here may allocate (device or pinned memory, events).
 int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, int h, int row_parts, int row_part,
-                uint8_t* d_rgb, size_t stride, uint32_t* d_hits, rt_stats* stats, hipStream_t st) {
+                uint8_t* d_rgb, size_t stride, uint32_t* d_hits, rt_stats* stats, hipStream_t st, unsigned char* ws = nullptr) {
     if (row_parts < 1 || row_part < 0 || row_part >= row_parts) return fail(RT_ERR_INVALID, "bad interleave %d/%d", row_part, row_parts);
     if (!sc || !cam) return fail(RT_ERR_INVALID, "NULL scene or camera");
     if (w <= 0 || h <= 0 || x0 < 0 || y0 < 0 || x0 + w > cam->image_width || y0 + h > cam->image_height)
@@ -851,19 +870,66 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
     }
     const int D = sc->has_reflective ? depth : 0;   // without reflective materials no child ray is ever spawned
     int rc;
-    if ((rc = sc->b_ctl.ensure(sizeof(Control)))) return rc;
-    Control* ctl = (Control*)sc->b_ctl.p;
+    const int blocks_closest = ws ? std::min(sc->blocks_closest, RT_NOALLOC_BLOCKS) : sc->blocks_closest;
+    const int blocks_shadow = ws ? std::min(sc->blocks_shadow, RT_NOALLOC_BLOCKS) : sc->blocks_shadow;
     // per-wave scratch of the trace loops, sized for the largest resident grid of any kernel that runs them
-    const size_t max_waves = std::max<size_t>((size_t)std::max(sc->blocks_closest, sc->blocks_shadow) * (RT_TRACE_BLOCK / 64),
-                                              (size_t)sc->blocks_ordered * (RT_ORDERED_BLOCK / 64));
-    if ((rc = sc->b_spill.ensure(max_waves * (sc->stack_cap - RT_STACK_LDS) * 64 * sizeof(uint2)))) return rc;
-    uint2* spill = (uint2*)sc->b_spill.p;
+    const size_t max_waves = ws ? (size_t)std::max(blocks_closest, blocks_shadow) * (RT_TRACE_BLOCK / 64)
+                                : std::max<size_t>((size_t)std::max(sc->blocks_closest, sc->blocks_shadow) * (RT_TRACE_BLOCK / 64),
+                                                   (size_t)sc->blocks_ordered * (RT_ORDERED_BLOCK / 64));
+    const size_t spill_bytes = max_waves * (sc->stack_cap - RT_STACK_LDS) * 64 * sizeof(uint2);
     // candidate hits of rays whose subtrees were traced by other lanes (rt_traverse.h): 64 x RT_CAND_MAX per wave
-    if ((rc = sc->b_cand.ensure(max_waves * 64 * RT_CAND_MAX * sizeof(uint4)))) return rc;
-    uint4* cand = (uint4*)sc->b_cand.p;
+    const size_t cand_bytes = max_waves * 64 * RT_CAND_MAX * sizeof(uint4);
+    Control* ctl;
+    uint2* spill;
+    uint4* cand;
+    Pool ws_pool{};
+    uint32_t* ws_mt = nullptr;
+    size_t ws_mt_bytes = 0;
+    if (ws) {
+        if (sc->needs_sequential_rng)
+            return fail(RT_ERR_UNSUPPORTED, "rt_render_tile_device_noalloc: scenes whose shading draws random numbers (area lights, rough materials) need per-thread frame stacks; use rt_render_tile_device");
+        if ((uint64_t)w * h * N > RT_NOALLOC_MAX_SAMPLES)
+            return fail(RT_ERR_INVALID, "rt_render_tile_device_noalloc: %llu pixel samples exceed the maximum of %u", (unsigned long long)w * h * N, RT_NOALLOC_MAX_SAMPLES);
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        size_t off = 0;
+        ctl = (Control*)(ws + off); off += up(sizeof(Control));
+        spill = (uint2*)(ws + off); off += up(spill_bytes);
+        cand = (uint4*)(ws + off); off += up(cand_bytes);
+        if (off + (1u << 20) > RT_NOALLOC_SCRATCH_BYTES)
+            return fail(RT_ERR_UNSUPPORTED, "rt_render_tile_device_noalloc: the scene's traversal stacks (%u entries per ray) do not fit the %u MiB static workspace", sc->stack_cap, RT_NOALLOC_SCRATCH_BYTES >> 20);
+        // the rest: records (104 B) + shadow slots (5 B each) of one chunk, and for N > 1 the generator state of its pixels
+        const size_t avail = RT_NOALLOC_SCRATCH_BYTES - off - 4096;
+        const size_t lights = std::min<size_t>(std::max<uint32_t>(sc->n_point_lights, 1), 4);
+        const size_t rec_bytes = 104 + 5 * lights;
+        const size_t per_pixel = (size_t)N * (D > 0 ? 2 : 1) * rec_bytes + (N > 1 ? (624 + (size_t)N) * 4 : 0);
+        const size_t pixels = (avail / per_pixel) & ~(size_t)63;
+        if (pixels < 64) return fail(RT_ERR_INVALID, "rt_render_tile_device_noalloc: one 8x8 tile at %d spp does not fit the static workspace", N);
+        const size_t R = pixels * N * (D > 0 ? 2 : 1), S = R * lights;
+        Pool& P = ws_pool;
+        P.ray0 = (float4*)(ws + off); off += R * 16;
+        P.ray1 = (float4*)(ws + off); off += R * 16;
+        P.hit0 = (uint4*)(ws + off); off += R * 16;
+        P.nrm = (float4*)(ws + off); off += R * 16;
+        P.link = (uint4*)(ws + off); off += R * 16;
+        P.color = (float4*)(ws + off); off += R * 16;
+        P.hit1 = (float2*)(ws + off); off += R * 8;
+        P.shadow_rec = (uint32_t*)(ws + off); off += S * 4;
+        P.shadow_lit = (uint8_t*)(ws + off); off += up(S);
+        P.cap_records = (uint32_t)R;
+        P.cap_shadow = (uint32_t)S;
+        if (N > 1) { ws_mt = (uint32_t*)(ws + off); ws_mt_bytes = pixels * (624 + (size_t)N) * 4; off += ws_mt_bytes; }
+        if (off > RT_NOALLOC_SCRATCH_BYTES) return fail(RT_ERR_HIP, "internal: static workspace layout overruns (%zu bytes)", off);
+    } else {
+        if ((rc = sc->b_ctl.ensure(sizeof(Control)))) return rc;
+        ctl = (Control*)sc->b_ctl.p;
+        if ((rc = sc->b_spill.ensure(spill_bytes))) return rc;
+        spill = (uint2*)sc->b_spill.p;
+        if ((rc = sc->b_cand.ensure(cand_bytes))) return rc;
+        cand = (uint4*)sc->b_cand.p;
+    }
 
-    const bool want_sync = stats != nullptr || (sc->opt_flags & RT_FLAG_TIMING) || D > 0 || sc->needs_sequential_rng;
-    Timer tm{sc, st, (sc->opt_flags & RT_FLAG_TIMING) != 0};
+    const bool want_sync = stats != nullptr || (!ws && (sc->opt_flags & RT_FLAG_TIMING)) || D > 0 || sc->needs_sequential_rng;
+    Timer tm{sc, st, !ws && (sc->opt_flags & RT_FLAG_TIMING) != 0};
     const bool near = (sc->opt_flags & RT_FLAG_NEAR_FIRST) != 0 || sc->rebuilt;   // non-parity visiting order (rt.h)
     HIPCHK(hipMemsetAsync(ctl, 0, sizeof(Control), st));
 
@@ -876,17 +942,18 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
     const int tiles_per_row = (w + 7) / 8, tile_rows_all = (h + 7) / 8;
     const int tile_rows = row_part < tile_rows_all ? (tile_rows_all - row_part + row_parts - 1) / row_parts : 0;
     const uint32_t total_tiles = (uint32_t)tiles_per_row * tile_rows;
-    if (!sc->needs_sequential_rng) {
+    if (!sc->needs_sequential_rng && !ws) {
         // records: one per primary sample, and with child rays about twice that (a chunk that overflows is redone
         // with half the pixels): room for four per sample of the largest chunk
         const uint64_t chunk = std::min<uint64_t>((uint64_t)total_tiles * 64 * N, sc->opt_chunk_samples);
         if ((rc = ensure_pool(sc, D > 0 ? 4 * chunk : chunk))) return rc;
     }
-    const Pool& P = sc->pool;
+    const Pool& P = ws ? ws_pool : sc->pool;
     // tiles per chunk: bounded by the chunk option, the record pool and the shadow pool
     uint64_t max_samples = std::min<uint64_t>(sc->opt_chunk_samples, D > 0 ? P.cap_records / 2 : P.cap_records);
     if (sc->n_point_lights) max_samples = std::min<uint64_t>(max_samples, P.cap_shadow / sc->n_point_lights);
     uint32_t tiles_per_chunk = (uint32_t)std::max<uint64_t>(1, max_samples / (64ull * N));
+    if (ws && N > 1) tiles_per_chunk = std::min<uint32_t>(tiles_per_chunk, (uint32_t)(ws_mt_bytes / (64 * (624 + (size_t)N) * 4)));
     if (!sc->needs_sequential_rng && (uint64_t)tiles_per_chunk * 64 * N > P.cap_records) return fail(RT_ERR_OVERFLOW, "record pool too small for one 8x8 tile at %d spp", N);
 
     uint32_t chunks = 0, retries = 0;
@@ -934,8 +1001,8 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
             k_raygen_single<<<(g.n_idx + 255) / 256, 256, 0, st>>>(dc, g, P);
         } else {
             const size_t strideT = g.n_idx;
-            if ((rc = sc->b_mt.ensure(strideT * (624 + (size_t)N) * 4))) return rc;
-            uint32_t* mt = (uint32_t*)sc->b_mt.p;
+            if (!ws && (rc = sc->b_mt.ensure(strideT * (624 + (size_t)N) * 4))) return rc;
+            uint32_t* mt = ws ? ws_mt : (uint32_t*)sc->b_mt.p;
             k_raygen_multi<<<(g.n_idx + 255) / 256, 256, 0, st>>>(dc, g, P, mt, mt + strideT * 624, strideT);
         }
         if ((rc = tm.end())) return rc;
@@ -944,8 +1011,8 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         // of generation d and the child rays of generation d + 1 are independent of each other (k_trace_mixed)
         const bool merge = !(sc->opt_flags & RT_FLAG_SEPARATE_LAUNCHES);
         if ((rc = tm.begin(TC_CLOSEST))) return rc;
-        if (near) k_trace_closest<true><<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, 0, spill, cand);
-        else k_trace_closest<false><<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, 0, spill, cand);
+        if (near) k_trace_closest<true><<<blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, 0, spill, cand);
+        else k_trace_closest<false><<<blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, 0, spill, cand);
         if ((rc = tm.end())) return rc;
         for (int d = 0; d <= D; d++) {
             if ((rc = tm.begin(TC_SHADE))) return rc;
@@ -954,20 +1021,20 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
             if ((rc = tm.end())) return rc;
             if (d < D && sc->n_point_lights && merge) {
                 if ((rc = tm.begin(TC_CLOSEST))) return rc;      // (timed under "closest": both kinds of ray)
-                if (near) k_trace_mixed<true><<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, d + 1, spill, cand);
-                else k_trace_mixed<false><<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, d + 1, spill, cand);
+                if (near) k_trace_mixed<true><<<blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, d + 1, spill, cand);
+                else k_trace_mixed<false><<<blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, d + 1, spill, cand);
                 if ((rc = tm.end())) return rc;
                 continue;
             }
             if (sc->n_point_lights) {
                 if ((rc = tm.begin(TC_SHADOW))) return rc;
-                k_trace_shadow<<<sc->blocks_shadow, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, spill, cand);
+                k_trace_shadow<<<blocks_shadow, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d, spill, cand);
                 if ((rc = tm.end())) return rc;
             }
             if (d < D) {
                 if ((rc = tm.begin(TC_CLOSEST))) return rc;
-                if (near) k_trace_closest<true><<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d + 1, spill, cand);
-                else k_trace_closest<false><<<sc->blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d + 1, spill, cand);
+                if (near) k_trace_closest<true><<<blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d + 1, spill, cand);
+                else k_trace_closest<false><<<blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, d + 1, spill, cand);
                 if ((rc = tm.end())) return rc;
             }
         }
@@ -1151,6 +1218,18 @@ int rt_upload_scene_ex(int device, const rt_scene_desc* scene, uint32_t upload_f
         hipEventCreateWithFlags(&sc->ev_async, hipEventDisableTiming) != hipSuccess) { rt_free_scene(sc); return fail(RT_ERR_HIP, "hipEventCreate failed"); }
     rc = guarded([&] { return build_device_scene(sc, scene, upload_flags); });
     if (rc) { rt_free_scene(sc); return rc; }
+    if (device < RT_MAX_DEVICES) {
+        // this GPU's copy of the static workspace (rt_render_tile_device_noalloc): asked for once per device, with
+        // that device current (hipSetDevice above); every GPU has its own copy at its own address
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[device]) {
+            unsigned char* ptr = nullptr;
+            const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !ptr) { rt_free_scene(sc); return fail(RT_ERR_HIP, "hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(e)); }
+            g_scratch_ptr[device] = ptr;
+        }
+        sc->static_ws = g_scratch_ptr[device];
+    }
     // persistent grids: as many workgroups as are resident at once (RT_TRACE_BLOCKS_PER_CU caps it, for occupancy experiments)
     int per_cu = 0, cap = 8;
     if (const char* e = getenv("RT_TRACE_BLOCKS_PER_CU")) cap = std::max(1, std::min(8, atoi(e)));
@@ -1216,6 +1295,16 @@ int rt_render_tile_rows_device(rt_scene* s, const rt_camera_desc* cam, int x0, i
     return guarded([&] {
         return render_impl(s, cam, x0, y0, tile_w, tile_h, row_parts, row_part, (uint8_t*)d_rgb_out, rgb_row_stride_bytes,
                            (uint32_t*)d_hit_id_out, stats, st);
+    });
+}
+
+int rt_render_tile_device_noalloc(rt_scene* s, const rt_camera_desc* cam, int x0, int y0, int tile_w, int tile_h, void* d_rgb_out,
+                                  size_t rgb_row_stride_bytes, void* d_hit_id_out, void* hip_stream) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is NULL");
+    if (!s->static_ws) return fail(RT_ERR_UNSUPPORTED, "rt_render_tile_device_noalloc: no static workspace on device %d", s->device);
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
+    return guarded([&] {
+        return render_impl(s, cam, x0, y0, tile_w, tile_h, 1, 0, (uint8_t*)d_rgb_out, rgb_row_stride_bytes, (uint32_t*)d_hit_id_out, nullptr, st, s->static_ws);
     });
 }
 

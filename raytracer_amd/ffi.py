@@ -340,6 +340,8 @@ def hip_lib():
         L.rt_render_tile_rows_device.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_int, C.c_int,
                                                  C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Stats),
                                                  C.c_void_p]
+        L.rt_render_tile_device_noalloc.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_int, C.c_int,
+                                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rt_debug_fetch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]
         L.rt_sync.argtypes = [C.c_void_p]
         L.rt_free_scene.argtypes = [C.c_void_p]
@@ -393,6 +395,12 @@ class DeviceScene:
                                                C.c_void_p(d_hits_ptr) if d_hits_ptr else None,
                                                C.byref(stats) if stats is not None else None,
                                                C.c_void_p(stream) if stream else None))
+
+    def render_device_noalloc(self, cam, x0, y0, w, h, d_rgb_ptr, row_stride, d_hits_ptr=None, stream=None):
+        """rt_render_tile_device_noalloc: the same into device memory without any allocation (static workspace)."""
+        _check(hip_lib().rt_render_tile_device_noalloc(self._h, C.byref(cam), x0, y0, w, h, C.c_void_p(d_rgb_ptr), row_stride,
+                                                       C.c_void_p(d_hits_ptr) if d_hits_ptr else None,
+                                                       C.c_void_p(stream) if stream else None))
 
     def render_rows_device(self, cam, x0, y0, w, h, row_parts, row_part, d_rgb_ptr, row_stride, d_hits_ptr=None,
                            stats=None, stream=None):
