@@ -238,6 +238,14 @@ enum {
     RT_FLAG_TIMING = 1u << 0,  /* bracket kernels with HIP events -> rt_stats.ms_* */
     RT_FLAG_SEPARATE_LAUNCHES = 1u << 1,  /* trace the shadow rays of a generation and the child rays of the next
                                              in two launches instead of one (diagnostic; same results) */
+    RT_FLAG_PER_BOUNCE_LAUNCHES = 1u << 3,  /* always trace generation by generation: one trace launch per bounce, shading and
+                                               shadow slots between them */
+    RT_FLAG_ONE_LAUNCH = 1u << 4,           /* always trace all generations of a chunk in ONE persistent launch in which every
+                                               trace workgroup shades the rays it finishes and traces what they spawn.
+                                               With neither flag the library chooses by size: one launch for renders of up to
+                                               2^20 primary rays (fewer launches, no per-generation end games), per bounce
+                                               above (higher throughput).  Same rays, same results, byte for byte, either way.
+                                               Ignored where shading draws random numbers and by the _noalloc entry point. */
     RT_FLAG_NEAR_FIRST = 1u << 2          /* NON-PARITY mode (off by default): closest-hit rays visit the children of a
                                              BVH node nearest first instead of in the fixed left-then-right order of
                                              IntersectTopBVH / IntersectMeshBVH (raytracer.cpp:749-753, 802-806).

@@ -20,6 +20,7 @@
 #include "rt.h"
 #include "rt_kernels.h"
 #include "rt_ordered.h"
+#include "rt_mega.h"
 #include "rt_upload.h"
 #include "rt_rebuild.h"
 
@@ -129,6 +130,7 @@ struct rt_scene {
     Pool pool{};
     DevBuf b_ray0, b_ray1, b_hit0, b_hit1, b_nrm, b_link, b_color, b_shadow_rec, b_shadow_lit;
     DevBuf b_ctl, b_spill, b_cand, b_mt, b_frames, b_fb, b_hits;
+    DevBuf b_wq, b_sq;          // rt_mega.h: work rings of the trace workgroups, rings to their shading waves
     Control* h_ctl = nullptr;   // pinned
     void* h_stage = nullptr;    // pinned staging for rt_render_tile's host outputs
     size_t h_stage_bytes = 0;
@@ -771,11 +773,12 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s, uint32_t upload_fla
 
 // The record pool grows to what a render needs, up to RT_OPT_POOL_RECORDS (27 GB at its default of 256 M records:
 // sized for 288 GB of HBM — large pools mean few chunks, hence few launches with an end game each).
-int ensure_pool(rt_scene* sc, uint64_t want_records) {
-    const size_t cap = (size_t)std::min<uint64_t>(sc->opt_pool_records, std::max<uint64_t>(want_records, 1ull << 16));
+int ensure_pool(rt_scene* sc, uint64_t want_records, uint64_t slack_records = 0, uint64_t slack_shadow = 0) {
+    // (slack: the slabs the shading waves of the one-launch pipeline hold but may not fill, rt_mega.h)
+    const size_t cap = (size_t)std::min<uint64_t>(sc->opt_pool_records, std::max<uint64_t>(want_records, 1ull << 16) + slack_records);
     if (sc->pool.cap_records >= cap && sc->pool.cap_records <= sc->opt_pool_records && sc->b_ray0.p) return RT_OK;
     const size_t lights = std::max<uint32_t>(sc->n_point_lights, 1);
-    const size_t cap_sh = cap * std::min<size_t>(lights, 4);
+    const size_t cap_sh = cap * std::min<size_t>(lights, 4) + (size_t)slack_shadow;
     int rc;
     if ((rc = sc->b_ray0.ensure(cap * 16)) || (rc = sc->b_ray1.ensure(cap * 16)) || (rc = sc->b_hit0.ensure(cap * 16)) ||
         (rc = sc->b_hit1.ensure(cap * 8)) || (rc = sc->b_nrm.ensure(cap * 16)) || (rc = sc->b_link.ensure(cap * 16)) ||
@@ -818,6 +821,7 @@ int ctl_status(uint32_t ov, uint32_t stack_cap) {
     if (ov & 32u) return fail(RT_ERR_HIP, "internal: a wave exceeded its round bound (rt_traverse.h)");
     if (ov & 16u) return fail(RT_ERR_HIP, "internal: a ray waited for its helpers beyond the bound (rt_traverse.h)");
     if (ov & 4u) return fail(RT_ERR_OVERFLOW, "traversal stack deeper than %u entries", stack_cap);
+    if (ov & 64u) return fail(RT_ERR_OVERFLOW, "work ring of a trace workgroup overflowed (rt_mega.h): render smaller tiles or set RT_FLAG_PER_BOUNCE_LAUNCHES");
     if (ov & 3u) return fail(RT_ERR_OVERFLOW, "ray pool overflow");
     return RT_OK;
 }
@@ -942,16 +946,39 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
     const int tiles_per_row = (w + 7) / 8, tile_rows_all = (h + 7) / 8;
     const int tile_rows = row_part < tile_rows_all ? (tile_rows_all - row_part + row_parts - 1) / row_parts : 0;
     const uint32_t total_tiles = (uint32_t)tiles_per_row * tile_rows;
+    // Which pipeline (rt_mega.h): all generations of a chunk in ONE launch for renders of up to RT_MEGA_MAX_PRIMARIES
+    // primary rays — launch count and end games dominate those — and the per-bounce pipeline for larger ones, whose
+    // throughput is higher (DESIGN.md §5 has the measurements).  RT_FLAG_PER_BOUNCE_LAUNCHES / RT_FLAG_ONE_LAUNCH
+    // force either.  The no-allocation variant keeps the per-bounce pipeline: its fixed pool has no room for the
+    // shading waves' slabs, and the rings are 400 MB.
+    uint64_t mega_max = RT_MEGA_MAX_PRIMARIES;
+    if (const char* e = getenv("RT_MEGA_MAX_PRIMARIES")) mega_max = strtoull(e, nullptr, 10);
+    bool mega = !ws && !sc->needs_sequential_rng && !(sc->opt_flags & (RT_FLAG_PER_BOUNCE_LAUNCHES | RT_FLAG_SEPARATE_LAUNCHES)) &&
+                      (sc->n_point_lights != 0 || D > 0) &&
+                      ((sc->opt_flags & RT_FLAG_ONE_LAUNCH) || (uint64_t)total_tiles * 64 * N <= mega_max);
+    if (mega) {
+        if ((rc = sc->b_wq.ensure((size_t)blocks_closest * (RT_MEGA_CQ_CAP + RT_MEGA_AQ_CAP) * 4))) return rc;
+        if ((rc = sc->b_sq.ensure((size_t)blocks_closest * RT_MEGA_TRACERS * RT_MEGA_SQ_CAP * 4))) return rc;
+    }
+    // what the shading waves' slabs may hold without using it: one slab per workgroup, and up to a batch's worth (64
+    // records with two children each; 64 x lights slots) at the end of every slab, a sixteenth of it
+    const uint64_t mega_slack_rec = (uint64_t)blocks_closest * RT_MEGA_REC_SLAB;
+    const uint64_t mega_slack_sh = (uint64_t)blocks_closest * std::max<uint64_t>(RT_MEGA_SH_SLAB, 1024ull * sc->n_point_lights);
     if (!sc->needs_sequential_rng && !ws) {
         // records: one per primary sample, and with child rays about twice that (a chunk that overflows is redone
         // with half the pixels): room for four per sample of the largest chunk
         const uint64_t chunk = std::min<uint64_t>((uint64_t)total_tiles * 64 * N, sc->opt_chunk_samples);
-        if ((rc = ensure_pool(sc, D > 0 ? 4 * chunk : chunk))) return rc;
+        if ((rc = ensure_pool(sc, D > 0 ? 4 * chunk : chunk, mega ? mega_slack_rec : 0, mega ? mega_slack_sh : 0))) return rc;
     }
     const Pool& P = ws ? ws_pool : sc->pool;
+    // (a pool capped — RT_OPT_POOL_RECORDS — below the shading waves' slabs plus the smallest pool ensure_pool makes: per bounce)
+    if (mega && (uint64_t)P.cap_records < mega_slack_rec + (1ull << 16)) mega = false;
     // tiles per chunk: bounded by the chunk option, the record pool and the shadow pool
-    uint64_t max_samples = std::min<uint64_t>(sc->opt_chunk_samples, D > 0 ? P.cap_records / 2 : P.cap_records);
-    if (sc->n_point_lights) max_samples = std::min<uint64_t>(max_samples, P.cap_shadow / sc->n_point_lights);
+    const uint64_t slack_rec = mega ? mega_slack_rec : 0, slack_sh = mega ? mega_slack_sh : 0;
+    const uint64_t usable_rec = P.cap_records > slack_rec ? P.cap_records - slack_rec : 0;
+    const uint64_t usable_sh = P.cap_shadow > slack_sh ? (mega ? (P.cap_shadow - slack_sh) / 17 * 16 : P.cap_shadow) : 0;
+    uint64_t max_samples = std::min<uint64_t>(sc->opt_chunk_samples, D > 0 ? usable_rec / 2 : usable_rec);
+    if (sc->n_point_lights) max_samples = std::min<uint64_t>(max_samples, usable_sh / sc->n_point_lights);
     uint32_t tiles_per_chunk = (uint32_t)std::max<uint64_t>(1, max_samples / (64ull * N));
     if (ws && N > 1) tiles_per_chunk = std::min<uint32_t>(tiles_per_chunk, (uint32_t)(ws_mt_bytes / (64 * (624 + (size_t)N) * 4)));
     if (!sc->needs_sequential_rng && (uint64_t)tiles_per_chunk * 64 * N > P.cap_records) return fail(RT_ERR_OVERFLOW, "record pool too small for one 8x8 tile at %d spp", N);
@@ -1010,6 +1037,24 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         // closest(0); then per generation: shade(d), and ONE launch for what shade(d) produced — the shadow slots
         // of generation d and the child rays of generation d + 1 are independent of each other (k_trace_mixed)
         const bool merge = !(sc->opt_flags & RT_FLAG_SEPARATE_LAUNCHES);
+        if (mega) {
+            // one launch traces every ray of the chunk: primaries, the children its shading waves spawn, the shadow slots
+            // tracing waves that take shadow slots first: their share of the work, about 0.7 L h / (1 + 0.7 L h) for L lights and
+            // a hit fraction h ~ 0.7 (an any-hit ray costs ~0.7 of a closest-hit ray); RT_MEGA_ANY_WAVES overrides (experiments)
+            const double sh = 0.5 * (double)sc->n_point_lights;
+            uint32_t any_waves = sc->n_point_lights ? (uint32_t)std::lround(RT_MEGA_TRACERS * sh / (1.0 + sh)) : 0u;
+            if (const char* e = getenv("RT_MEGA_ANY_WAVES")) any_waves = (uint32_t)atoi(e);
+            any_waves = std::min<uint32_t>(any_waves, RT_MEGA_TRACERS - 1);
+            const MegaArgs ma{(uint32_t*)sc->b_wq.p, (uint32_t*)sc->b_wq.p + (size_t)blocks_closest * RT_MEGA_CQ_CAP, (uint32_t*)sc->b_sq.p, n_primary, any_waves,
+                              getenv("RT_MEGA_STRICT") ? (uint32_t)atoi(getenv("RT_MEGA_STRICT")) : 0u};
+            if ((rc = tm.begin(TC_CLOSEST))) return rc;
+            if (near) k_trace_mega<true><<<blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, ma, spill, cand);
+            else k_trace_mega<false><<<blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, ma, spill, cand);
+            if ((rc = tm.end())) return rc;
+            if ((rc = tm.begin(TC_COMBINE))) return rc;
+            for (int d = D; d >= 0; d--) k_combine_mega<<<grid_flat, 256, 0, st>>>(sc->ds, P, ctl, d, n_primary);
+            if ((rc = tm.end())) return rc;
+        } else {
         if ((rc = tm.begin(TC_CLOSEST))) return rc;
         if (near) k_trace_closest<true><<<blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, 0, spill, cand);
         else k_trace_closest<false><<<blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, P, ctl, 0, spill, cand);
@@ -1041,6 +1086,7 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         if ((rc = tm.begin(TC_COMBINE))) return rc;
         for (int d = D; d >= 0; d--) k_combine<<<grid_flat, 256, 0, st>>>(sc->ds, P, ctl, d);
         if ((rc = tm.end())) return rc;
+        }
         if ((rc = tm.begin(TC_RESOLVE))) return rc;
         k_resolve<<<(g.n_idx + 255) / 256, 256, 0, st>>>(dc, g, P, sc->ds.tri_shade, inv_n, d_rgb, stride, d_hits);
         if ((rc = tm.end())) return rc;
@@ -1368,7 +1414,7 @@ void rt_free_scene(rt_scene* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (DevBuf* b : {&s->b_big, &s->b_nodes, &s->b_tris, &s->b_tri_shade, &s->b_vnormals, &s->b_objects, &s->b_top_prims, &s->b_planes,
                       &s->b_materials, &s->b_lights, &s->b_ray0, &s->b_ray1, &s->b_hit0, &s->b_hit1, &s->b_nrm, &s->b_link,
-                      &s->b_color, &s->b_shadow_rec, &s->b_shadow_lit, &s->b_ctl, &s->b_spill, &s->b_cand, &s->b_mt, &s->b_frames, &s->b_area_lights, &s->b_fb, &s->b_hits, &s->b_tri_rank})
+                      &s->b_color, &s->b_shadow_rec, &s->b_shadow_lit, &s->b_ctl, &s->b_spill, &s->b_cand, &s->b_mt, &s->b_frames, &s->b_area_lights, &s->b_fb, &s->b_hits, &s->b_tri_rank, &s->b_wq, &s->b_sq})
         b->release();
     for (auto& e : s->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }

@@ -19,7 +19,7 @@
 #define RF_MISS        1u
 #define RF_LIGHTS      2u    // local lighting is evaluated (not an exiting dielectric)
 #define RF_DEAD        4u    // padding lane of an edge tile: no ray
-#define RF_STRIDE_SHIFT 8     // link.w >> 8: distance between the record's shadow slots of consecutive lights (k_shade)
+#define RF_STRIDE_SHIFT 8     // link.w bits 8..23: distance between the record's shadow slots of consecutive lights (k_shade)
 
 struct Pool {
     float4*   ray0;        // origin.xyz, time
@@ -435,7 +435,7 @@ struct ShadowIO {
         const uint32_t r = P.shadow_rec[i];
         if (r == 0xFFFFFFFFu) return 0;                        // slot of a block that overflowed the pool (k_shade)
         const uint4 lkr = P.link[r];
-        const uint32_t light = (i - lkr.z) / (lkr.w >> RF_STRIDE_SHIFT);
+        const uint32_t light = (i - lkr.z) / ((lkr.w >> RF_STRIDE_SHIFT) & 0xFFFFu);
         const float4 r0 = P.ray0[r], r1 = P.ray1[r], nn = P.nrm[r];
         const float tHit = __uint_as_float(P.hit0[r].x);
         V3 o = mk(r0.x, r0.y, r0.z), d = mk(r1.x, r1.y, r1.z);
@@ -786,56 +786,59 @@ __device__ __forceinline__ V3 diffuse_specular(const DMaterial& mat, const DPoin
     return diffuse + spec;
 }
 
-// ApplyShading's colour expression (raytracer.cpp:1251-1377) for the records of
-// generation gen, children already combined.
+// ApplyShading's colour expression (raytracer.cpp:1251-1377) for one record of depth `gen`, children already combined.
+__device__ __forceinline__ void combine_record(const DScene& S, const Pool& P, uint32_t r, const uint4 lk, int gen) {
+    V3 color = mk(0, 0, 0);
+    if (lk.w & RF_MISS) {
+        if (gen == 0 && !(lk.w & RF_DEAD)) color = ldv(S.background);   // raytracer.cpp:393-400
+        P.color[r] = make_float4(color.x, color.y, color.z, 0.f);
+        return;
+    }
+    const float4 r0 = P.ray0[r], r1 = P.ray1[r], nn = P.nrm[r];
+    const float tHit = __uint_as_float(P.hit0[r].x);
+    V3 o = mk(r0.x, r0.y, r0.z), d = mk(r1.x, r1.y, r1.z), n = mk(nn.x, nn.y, nn.z);
+    const DMaterial& mat = S.materials[__float_as_int(nn.w) - 1];
+    ShadeCtx c;
+    shade_ctx(S, mat, o, d, tHit, n, c);
+    V3 child0 = mk(0, 0, 0), child1 = mk(0, 0, 0);   // ComputeColor beyond max depth: (0,0,0) (raytracer.cpp:384-386)
+    if (lk.x != RT_NO_CHILD) { float4 v = P.color[lk.x]; child0 = mk(v.x, v.y, v.z); }
+    if (lk.y != RT_NO_CHILD) { float4 v = P.color[lk.y]; child1 = mk(v.x, v.y, v.z); }
+    V3 km = ldv(mat.km);
+    if (c.type == RT_MAT_MIRROR) {
+        color = color + emul(km, child0);
+    } else if (c.type == RT_MAT_CONDUCTOR) {
+        V3 reflectColor = emul(km, child0);
+        color = color + reflectColor * c.Fr;
+    } else if (c.type == RT_MAT_DIELECTRIC) {
+        if (c.tir) {
+            color = color + emul(km, child0);
+        } else {
+            V3 reflectColor = emul(km, child0);
+            V3 refractColor = child1;
+            if (!c.entering) {
+                float dd = vlen(c.x - o);
+                refractColor.x *= rt_expf(-mat.absorb_coef[0] * dd);
+                refractColor.y *= rt_expf(-mat.absorb_coef[1] * dd);
+                refractColor.z *= rt_expf(-mat.absorb_coef[2] * dd);
+            }
+            color = (color + reflectColor * c.Fr) + refractColor * (1.0f - c.Fr);
+        }
+    }
+    if (lk.w & RF_LIGHTS) {
+        color = color + emul(ldv(S.ambient), ldv(mat.ka));
+        const uint32_t sK = (lk.w >> RF_STRIDE_SHIFT) & 0xFFFFu;
+        for (uint32_t l = 0; l < S.n_point_lights; l++) {
+            if (P.shadow_lit[lk.z + l * sK]) color = color + diffuse_specular(mat, S.point_lights[l], c.x, c.n_shading, c.w0);
+        }
+    }
+    P.color[r] = make_float4(color.x, color.y, color.z, 0.f);
+}
+
+// ... for the records of generation gen (contiguous in the per-bounce pipeline).
 __global__ void __launch_bounds__(256) k_combine(DScene S, Pool P, Control* ctl, int gen) {
     const uint32_t begin = ctl->gstart[gen], end = ctl->gstart[gen + 1];
-    for (uint32_t r = begin + blockIdx.x * blockDim.x + threadIdx.x; r < end; r += gridDim.x * blockDim.x) {
-        const uint4 lk = P.link[r];
-        V3 color = mk(0, 0, 0);
-        if (lk.w & RF_MISS) {
-            if (gen == 0 && !(lk.w & RF_DEAD)) color = ldv(S.background);   // raytracer.cpp:393-400
-            P.color[r] = make_float4(color.x, color.y, color.z, 0.f);
-            continue;
-        }
-        const float4 r0 = P.ray0[r], r1 = P.ray1[r], nn = P.nrm[r];
-        const float tHit = __uint_as_float(P.hit0[r].x);
-        V3 o = mk(r0.x, r0.y, r0.z), d = mk(r1.x, r1.y, r1.z), n = mk(nn.x, nn.y, nn.z);
-        const DMaterial& mat = S.materials[__float_as_int(nn.w) - 1];
-        ShadeCtx c;
-        shade_ctx(S, mat, o, d, tHit, n, c);
-        V3 child0 = mk(0, 0, 0), child1 = mk(0, 0, 0);   // ComputeColor beyond max depth: (0,0,0) (raytracer.cpp:384-386)
-        if (lk.x != RT_NO_CHILD) { float4 v = P.color[lk.x]; child0 = mk(v.x, v.y, v.z); }
-        if (lk.y != RT_NO_CHILD) { float4 v = P.color[lk.y]; child1 = mk(v.x, v.y, v.z); }
-        V3 km = ldv(mat.km);
-        if (c.type == RT_MAT_MIRROR) {
-            color = color + emul(km, child0);
-        } else if (c.type == RT_MAT_CONDUCTOR) {
-            V3 reflectColor = emul(km, child0);
-            color = color + reflectColor * c.Fr;
-        } else if (c.type == RT_MAT_DIELECTRIC) {
-            if (c.tir) {
-                color = color + emul(km, child0);
-            } else {
-                V3 reflectColor = emul(km, child0);
-                V3 refractColor = child1;
-                if (!c.entering) {
-                    float dd = vlen(c.x - o);
-                    refractColor.x *= rt_expf(-mat.absorb_coef[0] * dd);
-                    refractColor.y *= rt_expf(-mat.absorb_coef[1] * dd);
-                    refractColor.z *= rt_expf(-mat.absorb_coef[2] * dd);
-                }
-                color = (color + reflectColor * c.Fr) + refractColor * (1.0f - c.Fr);
-            }
-        }
-        if (lk.w & RF_LIGHTS) {
-            color = color + emul(ldv(S.ambient), ldv(mat.ka));
-            for (uint32_t l = 0; l < S.n_point_lights; l++) {
-                if (P.shadow_lit[lk.z + l * (lk.w >> RF_STRIDE_SHIFT)]) color = color + diffuse_specular(mat, S.point_lights[l], c.x, c.n_shading, c.w0);
-            }
-        }
-        P.color[r] = make_float4(color.x, color.y, color.z, 0.f);
-    }
+    for (uint32_t r = begin + blockIdx.x * blockDim.x + threadIdx.x; r < end; r += gridDim.x * blockDim.x)
+        combine_record(S, P, r, P.link[r], gen);
 }
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) {   // MathF.h:11-16

@@ -132,6 +132,7 @@
 #define RT_ROUND_CAP (1u << 22)   // WORKING rounds of one wave in one trace call (rounds a finished wave spends lingering do not
                                   // count); a 64 M-sample chunk needs ~2e5, so a stuck wave reports within seconds, not minutes
 #endif
+#define RT_MEGA_IDLE_CAP (1u << 27)    // rounds a wave of the one-launch pipeline may wait without a ray (~0.5 us each)
 #define RT_WAIT_ROUNDS_MAX 1000000u   // an owner never waits longer for its helpers (error 16 instead of a hang)
 #ifndef RT_LINGER_SPINS
 #define RT_LINGER_SPINS 20000    // rounds a finished wave keeps looking at the board while others of its workgroup work
@@ -333,9 +334,15 @@ __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int src) { return (ui
 //   (verdict = has / in-shadow).  MODE 2: load has one more argument, bool& any (set to the item's kind), and
 //   the IO tells how many 64-item blocks of closest-hit items precede the any-hit items (first_blocks,
 //   first_count): the cursor hands out the former strip-interleaved, then the latter block by block.
-template <int MODE, bool LINGER, bool NEAR, class IO>
+// MEGA (rt_mega.h: one launch for all generations of a chunk): MODE 2 with items that come from two sources — the
+// primary rays [begin, end) through the cursor as above, and a work ring of the workgroup that its shading wave
+// fills with the child rays and shadow slots of the rays this workgroup has finished (io.ring_*).  `exhausted` then
+// only means "no primary ray is left"; a wave leaves when, in addition, the workgroup's count of unfinished items
+// is zero (io.done()), and subtrees are donated while primaries are gone and the ring is empty.
+template <int MODE, bool LINGER, bool NEAR, class IO, bool MEGA = false>
 __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32_t end, uint32_t* cursor, TraceStack& st,
                                  unsigned long long& traced, unsigned long long* traced_any = nullptr) {
+    static_assert(!MEGA || (MODE == 2 && LINGER), "the one-launch pipeline runs the mixed loop of a trace workgroup");
     // MODE 0: closest hit, 1: any-hit, 2: mixed — every lane's item says which it is (rt_ordered.h, where the
     // lanes of a wave ask for both kinds at once); `lane_any` is then a per-lane value, otherwise a constant
     constexpr bool MIXED = MODE == 2;
@@ -393,10 +400,15 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
     // A large generation is cut into RT_PARTS contiguous partitions, each with a cursor of its own, and a
     // workgroup starts on partition blockIdx % RT_PARTS: the workgroups that share an XCD work on one part of
     // the image (of the record pool), so that XCD's L2 holds that part's share of the BVH instead of all of it.
-    const uint32_t parts = (LINGER && !MIXED && n_blocks >= RT_PARTS_MIN_BLOCKS) ? (uint32_t)RT_PARTS : 1u;
+    const uint32_t parts = (LINGER && (!MIXED || MEGA) && n_blocks >= RT_PARTS_MIN_BLOCKS) ? (uint32_t)RT_PARTS : 1u;
     const uint32_t part0 = LINGER ? blockIdx.x % parts : 0u;
     uint32_t parts_done = 0;     // wave-uniform: partitions this wave knows to be drained
     uint32_t stale = 0;          // wave-uniform: rounds with idle lanes since the last refill
+    uint32_t idle_rounds = 0;    // MEGA, wave-uniform: consecutive rounds without a ray in this wave (bounded)
+    // MEGA: a wave that takes shadow slots first runs with the any-hit kernel's phase thresholds, and an any-hit lane
+    // postpones as few leaves as there (its first accepted hit ends it) — per wave / per lane instead of per kernel
+    uint32_t exit_few = EXIT_FEW, exit_wait = EXIT_WAIT;
+    if constexpr (MEGA) { if (io.pref_any) { exit_few = RT_EXIT_FEW_ANY; exit_wait = RT_EXIT_WAIT_ANY; } }
     st.sp = 0;
 
     for (;;) {
@@ -412,15 +424,22 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
 #ifdef RT_SPLIT_ALWAYS
         const bool split_now = S.donate_ok != 0;     // test build: exercise the donation path all the time
 #else
-        const bool split_now = exhausted && S.donate_ok != 0;
+        bool split_now = exhausted && S.donate_ok != 0;
+        if constexpr (MEGA) split_now = split_now && io.ring_empty();   // idle lanes have nothing else to take
 #endif
+        if constexpr (MEGA) {
+            if (io.aborted()) break;
+        }
         round++;
         if (round > RT_ROUND_CAP) {                 // never spin forever on the GPU: report instead (error 32)
             st.overflow |= 32u;
+            if constexpr (MEGA) io.abort();
             RT_STAT(if (lane == 0) printf("[stuck] block %d wave slot %u: alive %llx helper %llx inmesh %llx donated %llx cur0 %x busy %u ready %u idle %u out[me] %u\n", (int)blockIdx.x, st.slot, (unsigned long long)__ballot(alive), (unsigned long long)__ballot(helper), (unsigned long long)__ballot(in_mesh), (unsigned long long)__ballot(donated), cur, st.blk[0], st.blk[1], st.blk[2], st.out_cnt[st.slot]);)
             break;
         }
-        if (split_now) {
+        // (MEGA: subtrees are posted only while split_now holds, which comes and goes with the work ring; posted
+        // subtrees are taken, and cancellations seen, in every round — an owner must never wait on a task nobody takes)
+        if (split_now || MEGA) {
             RT_CLK(s0);
             // (a) an idle lane takes a posted subtree
             if (!alive && st.blk[1] != 0) {
@@ -460,7 +479,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             RT_CLK(s1);
             // (b) the wave tells the workgroup how many of its lanes are idle
             {
-                const uint32_t n_idle_now = (uint32_t)__popcll(__ballot(!alive));
+                const uint32_t n_idle_now = split_now ? (uint32_t)__popcll(__ballot(!alive)) : 0u;
                 if (n_idle_now != idle_posted) {
                     if (lane == 0) atomicAdd(&st.blk[2], n_idle_now - idle_posted);   // unsigned wrap = signed difference
                     idle_posted = n_idle_now;
@@ -468,8 +487,8 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             }
             RT_CLK(s2);
             // (c) a busy lane posts the bottom-most entry of its mesh-level stack while idle lanes outnumber posted tasks
-            RT_STAT(if (alive && in_mesh && !no_donate && don_next < st.sp) { st.acc->n_elig++; if (!(st.blk[2] > st.blk[1])) st.acc->n_gate++; })
-            for (int pass = 0; pass < RT_DONATE_PASSES && alive && in_mesh && !no_donate && don_next < st.sp && st.blk[2] > st.blk[1] && st.blk[1] < st.n_board; pass++) {
+            RT_STAT(if (split_now && alive && in_mesh && !no_donate && don_next < st.sp) { st.acc->n_elig++; if (!(st.blk[2] > st.blk[1])) st.acc->n_gate++; })
+            for (int pass = 0; pass < RT_DONATE_PASSES && split_now && alive && in_mesh && !no_donate && don_next < st.sp && st.blk[2] > st.blk[1] && st.blk[1] < st.n_board; pass++) {
                 RT_STAT(if (st.lane == __ffsll((long long)__ballot(1)) - 1) st.acc->ts_post_iters++;)
                 uint32_t* rec = st.board + (atomicAdd(&st.blk[3], 1u) % st.n_board) * 16u;
                 const bool got_slot = atomicCAS(&rec[0], 0u, 1u) == 0u;
@@ -526,7 +545,24 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
 
         // ---- nothing to do in this wave: leave, or stay to help the workgroup
         const bool any_alive = __any(alive);
-        if (!any_alive && exhausted) {
+        if constexpr (MEGA) {
+            if (!any_alive) {
+                if (was_busy) {
+                    was_busy = false;
+                    if (lane == 0) atomicSub(&st.blk[0], 1u);
+                }
+                if (exhausted && io.done()) {                // no primary left, nothing unfinished in the workgroup
+                    if (idle_posted != 0 && lane == 0) atomicSub(&st.blk[2], idle_posted);
+                    break;
+                }
+                if (io.ring_empty() && st.blk[1] == 0) __builtin_amdgcn_s_sleep(16);
+                round--;                                     // waiting is not work
+                if (++idle_rounds > RT_MEGA_IDLE_CAP) { st.overflow |= 32u; io.abort(); break; }
+            } else {
+                idle_rounds = 0;
+            }
+        }
+        if (!MEGA && !any_alive && exhausted) {
             if (was_busy) {
                 was_busy = false;
                 if (lane == 0) atomicSub(&st.blk[0], 1u);
@@ -555,13 +591,13 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             // lanes sit on RT_LINK_DONE).  The phase ends for the WAVE when no lane can
             // (wave-uniform exit: the two phases must not be interleaved by the compiler).
             const bool leaf_here = (cur & RT_LINK_LEAF) != 0;
-            const bool want = !leaf_here || (in_mesh && cur < 0xFC000000u && qn < QCAP);
+            const bool want = !leaf_here || (in_mesh && cur < 0xFC000000u && qn < ((MEGA && lane_any) ? (uint32_t)RT_LEAF_QUEUE_ANY : QCAP));
             {   // Leave the node phase also when only a few lanes still walk while others wait with queued
                 // leaves: the walkers keep their place and go on in the next node phase.  (A wave completes a
                 // step about every 1.3 us whatever the number of active lanes, so steps with few lanes cost
                 // as much as full ones.)
                 const uint32_t n_want = (uint32_t)__popcll(__ballot(want)), n_wait = (uint32_t)__popcll(__ballot(!want && qn != 0));
-                if (n_want == 0 || (n_want <= EXIT_FEW && n_wait >= EXIT_WAIT)) break;
+                if (n_want == 0 || (n_want <= exit_few && n_wait >= exit_wait)) break;
             }
             if (want) {
                 if (leaf_here) {
@@ -993,9 +1029,96 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             cur = RT_LINK_DONE;
             st.sp = 0;
         }
-        if (tpass != 0 || exhausted) break;
+        if constexpr (MEGA) io.flush(lane, lanes_below);   // finished rays: hits to the shading wave, the others off the workgroup's count
+        if (tpass != 0 || (exhausted && !MEGA)) break;
         // ---- refill idle lanes
         bool refilled = false;
+        if constexpr (MEGA) {
+            const uint64_t idle = __ballot(!alive);
+            uint32_t n_idle = (uint32_t)__popcll(idle);
+            stale = n_idle != 0 ? stale + 1 : 0;
+            if (n_idle >= (io.pref_any ? (uint32_t)RT_REFILL_MIN_ANY : (uint32_t)RT_REFILL_MIN) || stale > RT_REFILL_PATIENCE) {
+                stale = 0;
+                // every closest-hit ray in flight must find room in this wave's ring to the shading wave when it finishes
+                const uint32_t in_flight = (uint32_t)__popcll(__ballot(alive && !helper && !lane_any));
+                const uint32_t room = io.shade_room();
+                n_idle = room > in_flight ? min(n_idle, room - in_flight) : 0u;
+                const uint32_t rank = (uint32_t)__popcll(idle & lanes_below);
+                // Sources, in this wave's order of preference.  A wave that prefers shadow slots takes them, then child rays,
+                // then primaries; the others child rays, primaries, then shadow slots — so a wave mostly holds rays of
+                // one kind (neighbouring slots towards one light; or closest-hit rays of neighbouring pixels) and only
+                // mixes when its own kind has run dry.
+                uint32_t it = 0;
+                const uint32_t my_rank = !alive ? rank : 0xFFFFFFFFu;
+                uint32_t n_ring = 0;
+                if (n_idle && io.pref_any) n_ring += io.ring_take(true, n_idle, lane, my_rank, 0u, it);
+                // (strict roles: a shadow wave takes closest-hit work only once the primaries are gone)
+                const bool other_kind_ok = !io.strict || !io.pref_any || exhausted;
+                if (n_idle > n_ring && other_kind_ok) n_ring += io.ring_take(false, n_idle - n_ring, lane, my_rank, n_ring, it);
+                uint32_t n_prim = (exhausted || n_idle <= n_ring || !other_kind_ok) ? 0u : n_idle - n_ring;
+                bool mine = !alive && rank < n_ring;
+                if (n_prim != 0) {
+                    const uint32_t part = (part0 + parts_done) % parts;
+                    const uint32_t pb0 = (uint32_t)((uint64_t)n_blocks * part / parts);
+                    const uint32_t pnb = (uint32_t)((uint64_t)n_blocks * (part + 1u) / parts) - pb0, p_padded = pnb * 64u;
+                    io.count(n_prim, lane);                  // counted before they are taken: the count never runs low
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(cursor + part * RT_CURSOR_STRIDE, n_prim);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (base + n_prim >= p_padded) {
+                        parts_done++;
+                        if (lane == 0) atomicMax(&st.blk[4], parts_done);
+                        if (parts_done >= parts) { exhausted = true; RT_STAT(st.acc->clk_exhausted = wall_clock64();) }
+                        else stale = RT_REFILL_PATIENCE + 1u;
+                    }
+                    bool valid = false;
+                    if (!alive && rank >= n_ring && rank < n_idle) {
+                        const uint32_t c = base + (rank - n_ring);
+                        if (c < p_padded) {
+                            const uint32_t strip = c / STRIP, within = c % STRIP;
+                            const uint32_t i = begin + (pb0 + strip % pnb) * 64u + (strip / pnb) * STRIP + within;
+                            if (i < end) { valid = true; it = i; }
+                        }
+                    }
+                    io.uncount(n_prim - (uint32_t)__popcll(__ballot(valid)), lane);
+                    mine = mine || valid;
+                }
+                if (!io.pref_any && n_idle > n_ring + n_prim && (!io.strict || exhausted)) {   // nothing else left for these lanes: shadow slots
+                    const uint32_t k = io.ring_take(true, n_idle - n_ring - n_prim, lane, my_rank, n_ring + n_prim, it);
+                    mine = mine || (!alive && rank >= n_ring + n_prim && rank < n_ring + n_prim + k);
+                }
+                int got = 0;
+                if (mine) {
+                    item = it;
+                    got = io.load(it, ro, rd, time, minT, has, out, lane_any);
+                }
+                io.loaded(mine, got, lane);                  // rays that needed no traversal are finished already
+                traced += __popcll(__ballot(got != 0));
+                if (traced_any) *traced_any += __popcll(__ballot(got != 0 && lane_any));
+                refilled = __any(got == 2);
+                if (got == 2) {
+                    fin = false;
+                    alive = true;
+                    helper = false;
+                    home = st.slot;
+                    st.sp = 0;
+                    in_mesh = false;
+                    donated = false;
+                    no_donate = false;
+                    qn = 0;
+                    ar.set(ro, rd);
+                    tmax = minT;
+                    cur = RT_LINK_DONE;
+                    if (S.top_root_link != RT_LINK_DONE) {
+                        float te;
+                        if (box_test(ar, S.top_rmin[0], S.top_rmin[1], S.top_rmin[2], S.top_rmax[0], S.top_rmax[1], S.top_rmax[2], tmax, te)) {
+                            cur = S.top_root_link;
+                            cur_t = te;
+                        }
+                    }
+                }
+            }
+        } else
         if (!exhausted) {
             const uint64_t idle = __ballot(!alive);
             const uint32_t n_idle = (uint32_t)__popcll(idle);

@@ -14,6 +14,8 @@ RT_MAT_NONE, RT_MAT_MIRROR, RT_MAT_CONDUCTOR, RT_MAT_DIELECTRIC = 0, 1, 2, 3
 RT_FLAG_TIMING = 1
 RT_FLAG_SEPARATE_LAUNCHES = 2
 RT_FLAG_NEAR_FIRST = 4        # non-parity visiting order, see include/rt.h
+RT_FLAG_PER_BOUNCE_LAUNCHES = 8
+RT_FLAG_ONE_LAUNCH = 16
 RT_UPLOAD_REBUILD_MESH_BVH = 1
 RT_UPDATE_VERIFY_MESHES = 1
 RT_OPT_FLAGS, RT_OPT_POOL_RECORDS, RT_OPT_CHUNK_SAMPLES, RT_OPT_STACK_CAP = 1, 2, 3, 4

@@ -98,6 +98,61 @@ def test_synthetic_glossy_and_area_light_vs_oracle(rt):
     assert st.rays_shadow == ctr.s_rays + (ctr.c_rays - ctr.rays_primary - ctr.rays_secondary)
 
 
+def test_one_launch_and_per_bounce_pipelines_agree(rt):
+    """rt_mega.h against rt_kernels.h: all generations of a chunk in one persistent launch (the default up to 2^20
+    primary rays) and one launch per bounce trace the same rays and give the same bytes — on synthetic scenes (each
+    also against the oracle), on reference scenes, with several chunks, and with a record pool small enough that
+    chunks overflow and are redone."""
+    from oracle import binding as ob
+    cases = [rt.scenes.spheres_scene(200, 150), rt.scenes.mesh_scene(grid=96, width=640, height=360),
+             rt.scenes.instanced_scene(grid=64, width=480, height=270), rt.scenes.spheres_scene(200, 150, num_samples=16, dof=True),
+             rt.scenes.deep_chain_scene()]
+    scenes = [(s.build(), True) for s in cases] + [(util.golden_scene(n), False) for n in ("hw1_cornellbox_recursive", "hw2_metal_glass_plates", "hw3_spheres_dof")]
+    for hs, check_oracle in scenes:
+        cam = hs.camera(0)
+        ds = rt.DeviceScene(hs, 0)
+        out = {}
+        for flags in (0, rt.RT_FLAG_ONE_LAUNCH, rt.RT_FLAG_PER_BOUNCE_LAUNCHES):
+            ds.set_option(rt.RT_OPT_FLAGS, flags | rt.RT_FLAG_TIMING)   # (rt_stats counts launches only with timing on)
+            st = rt.Stats()
+            rgb, hits = ds.render(cam, want_hits=True, stats=st)
+            # (a frame may take several chunks — many lights — and a chunk that overflows its pool is launched again)
+            out[flags] = (rgb, hits, (st.rays_primary, st.rays_secondary, st.rays_shadow), st.launches_shadow == 0 and st.launches_closest >= st.chunks)
+        one, per = out[rt.RT_FLAG_ONE_LAUNCH], out[rt.RT_FLAG_PER_BOUNCE_LAUNCHES]
+        assert one[3] and not per[3]
+        # the default: one launch for renders of up to 2^20 primary rays (rt.h: RT_FLAG_ONE_LAUNCH)
+        assert out[0][3] == (cam.image_width * cam.image_height * max(cam.num_samples, 1) <= 1 << 20)
+        for o in (out[0], one):
+            assert (o[0] == per[0]).all() and (o[1] == per[1]).all() and o[2] == per[2]
+        # several chunks per frame, and a pool that overflows (chunks are redone with fewer pixels)
+        ds.set_option(rt.RT_OPT_FLAGS, rt.RT_FLAG_ONE_LAUNCH | rt.RT_FLAG_TIMING)
+        ds.set_option(rt.RT_OPT_CHUNK_SAMPLES, 8192)
+        st = rt.Stats()
+        rgb, hits = ds.render(cam, want_hits=True, stats=st)
+        assert st.chunks > 1 and st.launches_closest >= st.chunks and st.launches_shadow == 0
+        assert (rgb == per[0]).all() and (hits == per[1]).all() and (st.rays_primary, st.rays_secondary, st.rays_shadow) == per[2]
+        ds.close()
+        if check_oracle:
+            o_rgb, o_hits, ctr = ob.render(hs, cam, want_hits=True)
+            assert (one[0] == o_rgb).all() and (one[1] == o_hits).all()
+            assert one[2] == (ctr.rays_primary, ctr.rays_secondary, ctr.s_rays)
+    # pool pressure: 600 000 records hold the shading waves' slabs (256 x 2048) and little else
+    hs = rt.scenes.instanced_scene(grid=32, width=320, height=200).build()
+    cam = hs.camera(0)
+    ds = rt.DeviceScene(hs, 0)
+    ds.set_option(rt.RT_OPT_FLAGS, rt.RT_FLAG_PER_BOUNCE_LAUNCHES)
+    a, _ = ds.render(cam)
+    ds.close()
+    ds = rt.DeviceScene(hs, 0)
+    ds.set_option(rt.RT_OPT_FLAGS, rt.RT_FLAG_ONE_LAUNCH | rt.RT_FLAG_TIMING)
+    ds.set_option(rt.RT_OPT_POOL_RECORDS, 600000)
+    st = rt.Stats()
+    b, _ = ds.render(cam, stats=st)
+    ds.close()
+    assert st.launches_shadow == 0 and st.chunks > 1
+    assert (a == b).all()
+
+
 def test_ragged_sizes_and_tiny_images(rt):
     """Edge tiles (w,h not multiples of 8), 1x1 and 1xN images."""
     from oracle import binding as ob
@@ -162,6 +217,7 @@ def test_full_size_properties_mesh1m(rt):
     hs = spec.build()
     cam = hs.camera(0)
     ds = rt.DeviceScene(hs, 0)
+    ds.set_option(rt.RT_OPT_FLAGS, rt.RT_FLAG_TIMING)              # (rt_stats counts launches only with timing on)
     st = rt.Stats()
     a, ha = ds.render(cam, want_hits=True, stats=st)
     b, hb = ds.render(cam, want_hits=True)
@@ -171,7 +227,15 @@ def test_full_size_properties_mesh1m(rt):
     assert st.rays_shadow == 2 * int(hit.sum())                    # 2 point lights per shaded hit, depth 0
     x0, y0, w, h = 840, 470, 256, 160
     win, hw = ds.render(cam, x0=x0, y0=y0, w=w, h=h, want_hits=True)
+    assert st.launches_closest == 1 and st.launches_shadow == 1    # a frame this size: the per-bounce pipeline
+    # ... and the one-launch pipeline (rt_mega.h) forced at full size: same bytes, ids and ray counts
+    ds.set_option(rt.RT_OPT_FLAGS, rt.RT_FLAG_ONE_LAUNCH | rt.RT_FLAG_TIMING)
+    s1 = rt.Stats()
+    c, hc = ds.render(cam, want_hits=True, stats=s1)
     ds.close()
+    assert s1.launches_closest == 1 and s1.launches_shadow == 0
+    assert (c == a).all() and (hc == ha).all()
+    assert (s1.rays_primary, s1.rays_secondary, s1.rays_shadow) == (st.rays_primary, st.rays_secondary, st.rays_shadow)
     assert (win == a[y0:y0 + h, x0:x0 + w]).all() and (hw == ha[y0:y0 + h, x0:x0 + w]).all()
     o_rgb, o_hits, _ = ob.render(hs, cam, x0=x0, y0=y0, w=w, h=h, want_hits=True)
     assert (win == o_rgb).all() and (hw == o_hits).all()
