@@ -13,6 +13,7 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VA
          "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" \
          "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $C --output-format csv -d $OUT/pass$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-rebuilt > $OUT/pass$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/pass$i.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $C --output-format csv -d $OUT/pass$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-extras > $OUT/pass$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/pass$i.log; exit 1; }
   echo "pass $i ok"
 done
+python3 $R/scripts/pmc_summary.py $OUT > $OUT/summary.txt
