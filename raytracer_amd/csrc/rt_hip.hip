@@ -1127,6 +1127,51 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         HIPCHK(hipEventRecord(sc->ev_async, st));
         sc->pending_check = true;
     }
+#ifdef RT_TIMELINE
+    if (want_sync) {
+        static uint32_t tlw[RT_TL_WAVES][RT_TL_BINS][8];
+        static unsigned long long tl[RT_TL_BINS][8];
+        if (hipMemcpyFromSymbol(tlw, HIP_SYMBOL(g_tl), sizeof(tlw)) == hipSuccess) {
+            std::memset(tl, 0, sizeof(tl));
+            for (int w = 0; w < RT_TL_WAVES; w++) for (int b = 0; b < RT_TL_BINS; b++) for (int k = 0; k < 8; k++) tl[b][k] += tlw[w][b][k];
+            for (int b = 0; b < RT_TL_BINS; b++)
+                if (tl[b][0])
+                    fprintf(stderr, "[rt tl] %5d us: rounds %6llu slots/round %5.1f helpers/round %4.1f | node steps %7llu lanes/step %5.1f | tri steps %6llu lanes/step %5.1f | drained %.2f\n", b * 10, tl[b][0],
+                            (double)tl[b][1] / tl[b][0], (double)tl[b][6] / tl[b][0], tl[b][2], tl[b][2] ? (double)tl[b][3] / tl[b][2] : 0.0, tl[b][4], tl[b][4] ? (double)tl[b][5] / tl[b][4] : 0.0, (double)tl[b][7] / tl[b][0]);
+            std::memset(tlw, 0, sizeof(tlw));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl), tlw, sizeof(tlw));
+            unsigned long long tt[8] = {0};
+            if (hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_tl_tail), sizeof(tt)) == hipSuccess && tt[5]) {
+                fprintf(stderr, "[rt tl tail] %llu rounds of waves with rays after the drain: per round sched %.2f node %.2f tri %.2f big %.2f trans+refill %.2f us\n", tt[5],
+                        tt[0] * 0.01 / tt[5], tt[1] * 0.01 / tt[5], tt[2] * 0.01 / tt[5], tt[3] * 0.01 / tt[5], tt[4] * 0.01 / tt[5]);
+                std::memset(tt, 0, sizeof(tt));
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_tail), tt, sizeof(tt));
+            }
+            static uint32_t lg[RT_TL_LOG][8];
+            uint32_t ln = 0;
+            if (hipMemcpyFromSymbol(&ln, HIP_SYMBOL(g_tl_log_n), 4) == hipSuccess && hipMemcpyFromSymbol(lg, HIP_SYMBOL(g_tl_log), sizeof(lg)) == hipSuccess) {
+                ln = std::min<uint32_t>(ln, RT_TL_LOG);
+                std::vector<uint32_t> order(ln);
+                for (uint32_t i = 0; i < ln; i++) order[i] = i;
+                std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lg[a][6] > lg[b][6]; });
+                fprintf(stderr, "[rt tl] %u rays finished after the cursor was drained; the last 40 to finish:\n", ln);
+                for (uint32_t i = 0; i < ln && i < 40; i++) {
+                    const uint32_t* o = lg[order[i]];
+                    fprintf(stderr, "[rt tl ray] end@%7.1f us life %7.1f us | own node steps %5u leaves %4u | posts %3u wait-rounds %4u rounds %4u | %.2f us/step | item %u\n", o[6] * 0.01, o[2] * 0.01, o[0], o[1], o[3], o[4], o[5],
+                            o[0] ? o[2] * 0.01 / o[0] : 0.0, o[7]);
+                }
+                // by lifetime
+                unsigned long long hist[16] = {0}, steps[16] = {0};
+                for (uint32_t i = 0; i < ln; i++) { int b = 0; uint32_t us = lg[i][2] / 100; while (us > 1 && b < 15) { us >>= 1; b++; } hist[b]++; steps[b] += lg[i][0]; }
+                for (int b = 0; b < 16; b++) if (hist[b]) fprintf(stderr, "[rt tl life] %6d us+: %7llu rays, mean own node steps %.1f\n", 1 << b, hist[b], (double)steps[b] / hist[b]);
+            }
+            ln = 0;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_log_n), &ln, 4);
+            const unsigned long long big = ~0ull;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_t0), &big, sizeof(big));
+        }
+    }
+#endif
 #ifdef RT_TRACE_STATS
     if (want_sync) {
         const unsigned long long* d = sc->h_ctl->dbg;

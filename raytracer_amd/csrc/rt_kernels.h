@@ -330,43 +330,6 @@ __device__ __forceinline__ TraceStack make_stack(TraceLds<THREADS>& L, uint2* sp
 __device__ unsigned long long g_wave_dbg[8192][16];   // per wave of k_trace_closest (diagnostic build)
 #endif
 
-#ifdef RT_TRACE_STATS
-// diagnostic build: totals into ctl->dbg, per-wave breakdown into g_wave_dbg (printed by render_impl)
-__device__ void report_trace_stats(Control* ctl, const TraceStatsAcc& acc, unsigned long long traced, unsigned long long clk_start,
-                                   const TraceStack& st, const WaveWork& ww) {
-    atomicAdd(&ctl->dbg[0], acc.wave_node_steps); atomicAdd(&ctl->dbg[1], acc.lane_node_steps);
-    atomicAdd(&ctl->dbg[2], acc.wave_tri_steps); atomicAdd(&ctl->dbg[3], acc.lane_tri_steps);
-    atomicAdd(&ctl->dbg[4], acc.wave_outer);
-    if (ww.lane == 0) {
-        atomicAdd(&ctl->dbg[5], traced);
-        const unsigned long long clk_end = wall_clock64();
-        atomicMax(&ctl->dbg[10], ~clk_start); atomicMax(&ctl->dbg[11], clk_end); atomicAdd(&ctl->dbg[12], clk_end - clk_start); atomicAdd(&ctl->dbg[13], 1ull);
-        atomicMax(&ctl->dbg[14], clk_end - clk_start); atomicMax(&ctl->dbg[15], ~(clk_end - clk_start));
-        const uint32_t wg = blockIdx.x * (blockDim.x / 64) + ww.wave;
-        if (wg < 8192) {
-            unsigned long long* o = g_wave_dbg[wg];
-            o[0] = clk_end - clk_start; o[1] = acc.clk_exhausted ? acc.clk_exhausted - clk_start : 0; o[2] = acc.t_sched; o[3] = acc.t_node;
-            o[4] = acc.t_tri; o[5] = acc.t_big; o[6] = acc.t_trans; o[7] = 0; o[8] = 0; o[9] = 0;
-            o[10] = acc.n_donations; o[11] = acc.n_coop; o[12] = traced; o[13] = 0; o[14] = 0; o[15] = clk_start;
-        }
-    }
-    atomicAdd(&ctl->dbg[6], acc.n_elig); atomicAdd(&ctl->dbg[7], acc.n_gate); atomicAdd(&ctl->dbg[8], acc.n_casfail); atomicAdd(&ctl->dbg[9], acc.n_claim);
-    if (ww.lane == 0 && (blockIdx.x % 37) == 0 && ww.wave < 16) printf("[tail] block %d wave %u: life %.0f exhausted@%.0f | tail rounds %llu sched %.0f (claim %.0f announce %.0f post %.0f [%llu iters] rest %.0f) node %.0f tri %.0f big %.0f trans %.0f us\n", (int)blockIdx.x, ww.wave,
-        (wall_clock64() - clk_start) * 0.01, acc.clk_exhausted ? (acc.clk_exhausted - clk_start) * 0.01 : 0.0, acc.tl_rounds, acc.tl_sched * 0.01, acc.ts_a * 0.01, acc.ts_b * 0.01, acc.ts_c * 0.01, acc.ts_post_iters, acc.ts_d * 0.01, acc.tl_node * 0.01, acc.tl_tri * 0.01, acc.tl_big * 0.01, acc.tl_trans * 0.01);
-    if (ww.lane == 0 && blockIdx.x == 0) printf("[board] block 0 wave %u: busy %u ready %u idle %u postcur %u\n", ww.wave, st.blk[0], st.blk[1], st.blk[2], st.blk[3]);
-    {   // step counts live in whichever lane was first active: sum them per wave (after lane 0's plain stores above)
-        __threadfence();
-        const uint32_t wg = blockIdx.x * (blockDim.x / 64) + ww.wave;
-        if (wg < 8192) {
-            unsigned long long* o = g_wave_dbg[wg];
-            if (acc.wave_outer) atomicAdd(&o[7], acc.wave_outer);
-            if (acc.wave_node_steps) { atomicAdd(&o[8], acc.wave_node_steps); atomicAdd(&o[13], acc.lane_node_steps); }
-            if (acc.wave_tri_steps) { atomicAdd(&o[9], acc.wave_tri_steps); atomicAdd(&o[14], acc.lane_tri_steps); }
-        }
-    }
-}
-#endif
-
 // FindClosestHit's search part (raytracer.cpp:405-444) for generation `gen`.
 struct ClosestIO {
     const DScene& S;

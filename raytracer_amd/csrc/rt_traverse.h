@@ -106,7 +106,10 @@
 #define RT_REFILL_MIN_ANY 48
 #endif
 #ifndef RT_DONATE_PASSES
-#define RT_DONATE_PASSES 16      // stack entries a busy lane may post per round (helpers included, so a subtree fans out)
+#define RT_DONATE_PASSES 4       // stack entries a busy lane may post per round (helpers included, so a subtree fans out)
+#endif
+#ifndef RT_TAIL_STEPS
+#define RT_TAIL_STEPS 16         // node steps per round once the cursor is drained: the wave then looks at the task board that often
 #endif
 #ifndef RT_REFILL_PATIENCE
 #define RT_REFILL_PATIENCE 2     // rounds a wave waits for RT_REFILL_MIN idle lanes before it refills the ones it has
@@ -169,6 +172,26 @@ __device__ unsigned long long g_rayhist[2][20];   // [0]: rays by log2(leaves vi
 #define RT_STAT(x)
 #define RT_RAYHIST(x)
 #define RT_CLK(v)
+#endif
+
+// Diagnostic build only (-DRT_TIMELINE=mode): chip-wide activity of the trace kernel of that MODE over time, in 10-us
+// bins: rounds, ray slots in use, node steps and their active lanes, triangle steps and theirs.  A few atomics per
+// round: light enough to leave the timing alone (unlike RT_TRACE_STATS).
+#ifdef RT_TIMELINE
+#define RT_TL_BINS 256
+#define RT_TL_WAVES 4096
+__device__ uint32_t g_tl[RT_TL_WAVES][RT_TL_BINS][8];   // a row per wave: plain read-modify-writes by its lane 0, summed on the host
+__device__ unsigned long long g_tl_t0 = ~0ull;
+// rays (owners) that finish after the cursor was drained: own node steps, leaves queued, lifetime, subtrees given away, rounds spent waiting for helpers
+#define RT_TL_LOG 262144
+__device__ uint32_t g_tl_log[RT_TL_LOG][8];
+__device__ uint32_t g_tl_log_n;
+__device__ unsigned long long g_tl_tail[8];   // after the drain, summed over waves with rays: ticks in sched / node / tri / big / transitions, rounds
+#define RT_TLC(v) const unsigned long long v = (unsigned long long)wall_clock64()
+#define RT_TL(...) __VA_ARGS__
+#else
+#define RT_TL(...)
+#define RT_TLC(v)
 #endif
 
 typedef float f4a __attribute__((ext_vector_type(4)));
@@ -410,9 +433,30 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
     uint32_t exit_few = EXIT_FEW, exit_wait = EXIT_WAIT;
     if constexpr (MEGA) { if (io.pref_any) { exit_few = RT_EXIT_FEW_ANY; exit_wait = RT_EXIT_WAIT_ANY; } }
     st.sp = 0;
+    RT_TL(unsigned long long tl_t0 = 0; uint32_t tl_ns = 0, tl_nl = 0, tl_ts = 0, tl_tlanes = 0;)
+    RT_TL(unsigned long long tlt[6] = {0, 0, 0, 0, 0, 0};)
+    RT_TL(unsigned long long tlr_t0 = 0; uint32_t tlr_nodes = 0, tlr_leaves = 0, tlr_posts = 0, tlr_waits = 0, tlr_rounds = 0;)
+    RT_TL(if (MODE == RT_TIMELINE) { const unsigned long long now = (unsigned long long)wall_clock64(); if (lane == 0) atomicMin(&g_tl_t0, now); tl_t0 = now; })
 
     for (;;) {
         RT_CLK(c0);
+        RT_TLC(q0);
+        RT_TL(if (alive && !helper) tlr_rounds++;)
+        RT_TL(if (MODE == RT_TIMELINE) {
+            const unsigned long long t0g = *(volatile unsigned long long*)&g_tl_t0;
+            const uint32_t bin = (uint32_t)min((unsigned long long)(RT_TL_BINS - 1), ((unsigned long long)wall_clock64() - t0g) / 1000ull);
+            const uint32_t na = (uint32_t)__popcll(__ballot(alive)), nh = (uint32_t)__popcll(__ballot(alive && helper));
+            for (int off = 32; off != 0; off >>= 1) {   // the counts sit in whichever lane was first active in a step
+                tl_ns += (uint32_t)__shfl_xor((int)tl_ns, off); tl_nl += (uint32_t)__shfl_xor((int)tl_nl, off);
+                tl_ts += (uint32_t)__shfl_xor((int)tl_ts, off); tl_tlanes += (uint32_t)__shfl_xor((int)tl_tlanes, off);
+            }
+            const uint32_t wv = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+            if (lane == 0 && wv < RT_TL_WAVES) {
+                uint32_t* o = g_tl[wv][bin];
+                o[0] += 1u; o[1] += na; o[2] += tl_ns; o[3] += tl_nl; o[4] += tl_ts; o[5] += tl_tlanes; o[6] += nh; o[7] += exhausted ? 1u : 0u;
+            }
+            tl_ns = tl_nl = tl_ts = tl_tlanes = 0;
+        })
         if (LINGER && !exhausted) {                  // partitions other waves of the workgroup have seen drained
             const uint32_t d = st.blk[4];
             if (d > parts_done) {
@@ -423,8 +467,13 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         // ---- subtree donation over the workgroup's task board (see the header)
 #ifdef RT_SPLIT_ALWAYS
         const bool split_now = S.donate_ok != 0;     // test build: exercise the donation path all the time
+#elif defined(RT_NO_DONATE)
+        const bool split_now = false;                // experiment: no end-game machinery at all
 #else
-        bool split_now = exhausted && S.donate_ok != 0;
+        // (not in the any-hit kernel: shadow rays end at their first hit, few are long enough to be worth splitting, and
+        // the kernel is 10 % faster without the board: 0.86 -> 0.77 ms on the 1080p mesh frame.  Any-hit rays of the
+        // mixed kernels still take part.)
+        bool split_now = !ANY_ONLY && exhausted && S.donate_ok != 0;
         if constexpr (MEGA) split_now = split_now && io.ring_empty();   // idle lanes have nothing else to take
 #endif
         if constexpr (MEGA) {
@@ -515,6 +564,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                         rec[0] = 2u;                         // ready
                         atomicAdd(&st.blk[1], 1u);
                         RT_STAT(st.acc->n_donations++;)
+                        RT_TL(tlr_posts++;)
                     } else {
                         rec[0] = 0u;                         // the entry is culled by now: nothing to give
                     }
@@ -584,7 +634,9 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
 
         // ---- node phase: collapsed interior records of either level; mesh leaves are queued
         RT_CLK(c1);
+        RT_TLC(q1);
         RT_STAT(if (st.lane == __ffsll((long long)__ballot(1)) - 1) st.acc->wave_outer++;)
+        uint32_t phase_steps = 0;    // wave-uniform
         for (;;) {
             // A lane can make progress here while it sits on an interior record, or on a mesh
             // leaf it still has queue room for (big leaves wait for the triangle phase; idle
@@ -598,15 +650,21 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 // as much as full ones.)
                 const uint32_t n_want = (uint32_t)__popcll(__ballot(want)), n_wait = (uint32_t)__popcll(__ballot(!want && qn != 0));
                 if (n_want == 0 || (n_want <= exit_few && n_wait >= exit_wait)) break;
+                // end game (subtrees are being donated): short node phases, so that posted subtrees are taken and
+                // new ones posted every few steps instead of once per ~30 — a long ray fans out over the idle lanes
+                if (split_now && ++phase_steps > (uint32_t)RT_TAIL_STEPS) break;
             }
             if (want) {
                 if (leaf_here) {
+                    RT_TL(tlr_leaves++;)
                     RT_STAT(st.acc->ray_leaves++;)
                     st.q[qn * 64 + st.lane] = make_uint2(cur, __float_as_uint(cur_t));
                     qn++;
                     cur = st.pop(tmax, cur_t);
                 }
                 if (!(cur & RT_LINK_LEAF)) {
+                    RT_TL({ const unsigned long long b_ = __ballot(1); if ((int)lane == __ffsll((long long)b_) - 1) { tl_ns++; tl_nl += (uint32_t)__popcll(b_); } })
+                    RT_TL(tlr_nodes++;)
                     RT_STAT(st.acc->ray_nodes++;)
                     RT_STAT({ unsigned long long m = __ballot(1); if (st.lane == __ffsll((long long)m) - 1) { st.acc->wave_node_steps++; st.acc->lane_node_steps += __popcll(m); st.acc->r_node_w++; st.acc->r_node_l += __popcll(m); } })
                     // The record holds, per axis, the four slots' min planes and their max planes (rt_device.h).  A
@@ -687,6 +745,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         }
 
         RT_CLK(c2);
+        RT_TLC(q2);
         // A triangle of the mesh in flight passed the test with bound tmax (leaf box entry te):
         // the owner accepts it as the reference does; a helper records it (see the header).
         // Returns true when the lane is finished with its ray / subtree (any-hit).
@@ -750,6 +809,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             // against the bound the previous one left, as the reference's loop does.  Past the leaf's end a lane
             // re-reads the leaf's first triangle.
             while (n != 0 && !fin) {
+                RT_TL({ const unsigned long long b_ = __ballot(1); if ((int)lane == __ffsll((long long)b_) - 1) { tl_ts++; tl_tlanes += (uint32_t)__popcll(b_); } })
                 RT_STAT({ unsigned long long m = __ballot(1); if (st.lane == __ffsll((long long)m) - 1) { st.acc->wave_tri_steps++; st.acc->lane_tri_steps += __popcll(m); st.acc->r_tri_w++; st.acc->r_tri_l += __popcll(m); } })
                 const uint32_t m = n < (uint32_t)RT_TRI_UNROLL ? n : (uint32_t)RT_TRI_UNROLL;
                 f4u ta[RT_TRI_UNROLL], tb[RT_TRI_UNROLL];
@@ -775,6 +835,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         }
         qn = 0;
         RT_CLK(c3);
+        RT_TLC(q3);
 
         // ---- a big leaf (>= RT_LEAF_BIG triangles, raytracer.cpp:183: an unsplittable node) waiting at `cur`.
         // It follows the queued leaves in visiting order.  Below RT_COOP_MIN triangles the lane tests it
@@ -856,6 +917,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         // rays make their first transition (top-level entry, raytracer.cpp:548-745) at once, in a second pass,
         // instead of sitting through a whole round before it
         RT_CLK(c4);
+        RT_TLC(q4);
         for (int tpass = 0;; tpass++) {
         bool finished = fin;
         if (alive && !fin) do {
@@ -869,6 +931,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 if (helper) { finished = true; break; }        // the donated subtree is done
                 bool redo = false;
                 if (donated) {
+                    RT_TL(if (st.out_cnt[st.slot] != 0) tlr_waits++;)
                     if (st.out_cnt[st.slot] != 0) {            // wait for the helpers (cur stays on the sentinel)
                         if (++wait_rounds > RT_WAIT_ROUNDS_MAX) { st.overflow |= 16u; } else break;
                     }
@@ -1019,6 +1082,14 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             } else {
                 RT_RAYHIST({ if (ANY_ONLY == RT_HIST_ANY) { atomicAdd(&g_rayhist[0][32 - __clz(st.acc->ray_leaves)], 1ull); atomicAdd(&g_rayhist[1][32 - __clz(st.acc->ray_nodes)], 1ull); } })
                 io.store(item, RT_ISANY ? fin : has, out, minT);
+                RT_TL(if (MODE == RT_TIMELINE && exhausted) {
+                    const uint32_t k_ = atomicAdd(&g_tl_log_n, 1u);
+                    if (k_ < RT_TL_LOG) {
+                        const unsigned long long now_ = (unsigned long long)wall_clock64();
+                        uint32_t* o_ = g_tl_log[k_];
+                        o_[0] = tlr_nodes; o_[1] = tlr_leaves; o_[2] = (uint32_t)(now_ - tlr_t0); o_[3] = tlr_posts; o_[4] = tlr_waits; o_[5] = tlr_rounds; o_[6] = (uint32_t)(now_ - *(volatile unsigned long long*)&g_tl_t0); o_[7] = item;
+                    }
+                })
             }
             RT_STAT(st.acc->ray_leaves = 0; st.acc->ray_nodes = 0;)
             alive = false;
@@ -1097,6 +1168,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 if (traced_any) *traced_any += __popcll(__ballot(got != 0 && lane_any));
                 refilled = __any(got == 2);
                 if (got == 2) {
+                    RT_TL(tlr_t0 = (unsigned long long)wall_clock64(); tlr_nodes = tlr_leaves = tlr_posts = tlr_waits = tlr_rounds = 0;)
                     fin = false;
                     alive = true;
                     helper = false;
@@ -1179,6 +1251,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 if (MIXED && traced_any) *traced_any += __popcll(__ballot(got != 0 && lane_any));
                 refilled = __any(got == 2);
                 if (got == 2) {
+                    RT_TL(tlr_t0 = (unsigned long long)wall_clock64(); tlr_nodes = tlr_leaves = tlr_posts = tlr_waits = tlr_rounds = 0;)
                     fin = false;
                     alive = true;
                     helper = false;
@@ -1203,6 +1276,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         }
         if (!refilled) break;
         }
+        RT_TL(if (MODE == RT_TIMELINE && exhausted && any_alive) { const unsigned long long q5 = (unsigned long long)wall_clock64(); tlt[0] += q1 - q0; tlt[1] += q2 - q1; tlt[2] += q3 - q2; tlt[3] += q4 - q3; tlt[4] += q5 - q4; tlt[5]++; })
         RT_STAT({ unsigned long long b = (c0 - st.acc->clk_start) / RT_HIST_TICKS; if (b >= RT_HIST_BINS) b = RT_HIST_BINS - 1;
                   if (ANY_ONLY != RT_HIST_ANY) { st.acc->r_node_w = 0; st.acc->r_tri_w = 0; }
                   if (st.acc->r_node_w) { atomicAdd(&g_hist[b][0], st.acc->r_node_w); atomicAdd(&g_hist[b][1], st.acc->r_node_l); }
@@ -1211,5 +1285,6 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         RT_STAT({ if (exhausted) { const unsigned long long c5 = wall_clock64(); st.acc->tl_rounds++; st.acc->tl_sched += c1 - c0; st.acc->tl_node += c2 - c1; st.acc->tl_tri += c3 - c2; st.acc->tl_big += c4 - c3; st.acc->tl_trans += c5 - c4; } })
         RT_STAT({ const unsigned long long c5 = wall_clock64(); st.acc->t_sched += c1 - c0; st.acc->t_node += c2 - c1; st.acc->t_tri += c3 - c2; st.acc->t_big += c4 - c3; st.acc->t_trans += c5 - c4; })
     }
+    RT_TL(if (MODE == RT_TIMELINE && lane == 0) { for (int k_ = 0; k_ < 6; k_++) atomicAdd(&g_tl_tail[k_], tlt[k_]); })
 }
 #undef RT_ISANY
