@@ -129,7 +129,7 @@ struct rt_scene {
     // work memory
     Pool pool{};
     DevBuf b_ray0, b_ray1, b_hit0, b_hit1, b_nrm, b_link, b_color, b_shadow_rec, b_shadow_lit;
-    DevBuf b_ctl, b_spill, b_cand, b_mt, b_frames, b_fb, b_hits;
+    DevBuf b_ctl, b_spill, b_cand, b_mt, b_frames, b_pstate, b_fb, b_hits;
     DevBuf b_wq, b_sq;          // rt_mega.h: work rings of the trace workgroups, rings to their shading waves
     Control* h_ctl = nullptr;   // pinned
     void* h_stage = nullptr;    // pinned staging for rt_render_tile's host outputs
@@ -992,9 +992,11 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         // depth-first so that the draws come in the reference's order (rt_ordered.h).  One launch, grid-stride.
         const uint32_t n_idx = total_tiles * 64u;
         const int grid = (int)std::min<uint32_t>((uint32_t)sc->blocks_ordered, (n_idx + RT_ORDERED_BLOCK - 1) / RT_ORDERED_BLOCK);
-        const size_t threads = (size_t)std::max(grid, 1) * RT_ORDERED_BLOCK;
+        // (a lane owns RT_ORDERED_SLOTS pixels at a time: generator, frame stack and loop state per slot)
+        const size_t threads = (size_t)std::max(grid, 1) * RT_ORDERED_BLOCK * RT_ORDERED_SLOTS;
         if ((rc = sc->b_mt.ensure(threads * (624 + (size_t)N) * 4))) return rc;
         if ((rc = sc->b_frames.ensure(threads * (size_t)(depth + 1) * OF_COUNT * 4))) return rc;
+        if ((rc = sc->b_pstate.ensure(threads * (size_t)PS_COUNT * 4))) return rc;
         OrderedArgs A;
         A.cam = dc;
         A.g = ChunkGeom{x0, y0, w, h, tiles_per_row, 0u, n_idx, row_parts, row_part};
@@ -1002,6 +1004,7 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         A.n_area_lights = sc->n_area_lights;
         A.mt_scratch = (uint32_t*)sc->b_mt.p;
         A.frames = (float*)sc->b_frames.p;
+        A.pstate = (uint32_t*)sc->b_pstate.p;
         A.inv_n = inv_n;
         A.rgb = d_rgb;
         A.row_stride = stride;
@@ -1459,7 +1462,7 @@ void rt_free_scene(rt_scene* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (DevBuf* b : {&s->b_big, &s->b_nodes, &s->b_tris, &s->b_tri_shade, &s->b_vnormals, &s->b_objects, &s->b_top_prims, &s->b_planes,
                       &s->b_materials, &s->b_lights, &s->b_ray0, &s->b_ray1, &s->b_hit0, &s->b_hit1, &s->b_nrm, &s->b_link,
-                      &s->b_color, &s->b_shadow_rec, &s->b_shadow_lit, &s->b_ctl, &s->b_spill, &s->b_cand, &s->b_mt, &s->b_frames, &s->b_area_lights, &s->b_fb, &s->b_hits, &s->b_tri_rank, &s->b_wq, &s->b_sq})
+                      &s->b_color, &s->b_shadow_rec, &s->b_shadow_lit, &s->b_ctl, &s->b_spill, &s->b_cand, &s->b_mt, &s->b_frames, &s->b_pstate, &s->b_area_lights, &s->b_fb, &s->b_hits, &s->b_tri_rank, &s->b_wq, &s->b_sq})
         b->release();
     for (auto& e : s->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }

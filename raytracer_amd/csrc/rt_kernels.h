@@ -123,17 +123,20 @@ struct MtGlobal {
         }
         idx = 624;
     }
-    __device__ void twist() {
-        for (uint32_t k = 0; k < 624; k++) {
-            uint32_t k1 = (k + 1 == 624) ? 0 : k + 1;
-            uint32_t km = (k + 397 >= 624) ? k + 397 - 624 : k + 397;
-            w(k) = mt_mix(w(k), w(k1), w(km));
-        }
-        idx = 0;
-    }
+    // std::mersenne_twister_engine regenerates all 624 words when the block is used up (_M_gen_rand) and then hands them
+    // out one by one.  Here word k of the new block is made when it is handed out: it needs the old words k, k + 1 and
+    // (k < 227) k + 397, none of them overwritten yet, or (k >= 227) the new word k - 227, made 227 draws ago — the same
+    // values in the same order, without a 624-word loop that stalls the 63 other lanes of a wave whenever one lane's
+    // block runs out (lanes of the depth-first pixel loop use up their blocks at different moments: 95 us per stall).
     __device__ __forceinline__ uint32_t next() {
-        if (idx >= 624) twist();
-        return mt_temper(w(idx++));
+        if (idx >= 624) idx = 0;
+        const uint32_t k = idx;
+        const uint32_t k1 = (k + 1 == 624) ? 0 : k + 1;
+        const uint32_t km = (k + 397 >= 624) ? k + 397 - 624 : k + 397;
+        const uint32_t v = mt_mix(w(k), w(k1), w(km));
+        w(k) = v;
+        idx = k + 1;
+        return mt_temper(v);
     }
     __device__ __forceinline__ float uniform() { return u32_to_unit(next()); }
     // uniform_int_distribution::_S_nd<uint64_t> (Lemire)

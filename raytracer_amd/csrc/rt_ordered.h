@@ -57,7 +57,31 @@ __device__ __forceinline__ V3 perturb_reflection(V3 r, float roughness, MtGlobal
     return normalize(rr);
 }
 
-// The request a lane has posted, and the answer it gets back.
+// ---- pixel slots.  A lane owns RT_ORDERED_SLOTS pixels at a time (slot k of lane l of a wave = item k * 64 + l of that
+// wave); everything a pixel needs between two of its rays lives in global memory, one 4-byte field per slot, stored
+// [field][slot] so that the 64 lanes of a wave read and write neighbouring words: the pixel's place in the loop
+// below (PS_*), its frame stack (OF_*), its generator.  The REQUEST a pixel has posted and the ANSWER it gets back
+// are fields too, so any lane of the wave can trace any slot's ray: the traversal loop sees the wave's 64 * SLOTS
+// requests as one list of items with a cursor, refills idle lanes from it and hands subtrees of long rays to idle
+// lanes — with one pixel per lane (the first version) every trace call was as slow as the slowest of 64 rays.
+#ifndef RT_ORDERED_SLOTS
+#define RT_ORDERED_SLOTS 1
+#endif
+enum {
+    PS_IDX,                                     // pixel index in the chunk; 0xFFFFFFFF: the slot is empty
+    PS_FLAGS,                                   // 1: ret_pending, 2: start_sample
+    PS_S, PS_DEPTH,
+    PS_ACC_R, PS_ACC_G, PS_ACC_B,
+    PS_RET_R, PS_RET_G, PS_RET_B,
+    PS_HIT_W0, PS_HIT_TRI,
+    PS_GEN_IDX, PS_TIME,
+    PS_REQ, PS_OX, PS_OY, PS_OZ, PS_DX, PS_DY, PS_DZ, PS_DIST,          // the request: OREQ_*, ray, InShadow's distance
+    PS_HAS, PS_T, PS_KIND, PS_TRI, PS_BETA, PS_GAMMA,                   // the answer
+    PS_COUNT
+};
+#define RT_SLOT_EMPTY 0xFFFFFFFFu
+
+// The request a slot has posted, and the answer it gets back (registers while a lane works on the slot).
 struct LaneTrace {
     int req;                     // OREQ_*
     V3 o, d;
@@ -66,66 +90,54 @@ struct LaneTrace {
     float t;
     uint32_t kind_index, tri;
     float beta, gamma;
-    uint32_t bad_item;           // set if an item ever reaches a lane other than its own
 };
 
-struct LaneClosestIO {
+// The wave's requests as items of the trace loop (trace_persistent MODE 2): item i = slot i of this wave.
+struct SlotMixedIO {
     const DScene& S;
-    LaneTrace& L;
-    uint32_t lane;
-    __device__ __forceinline__ int load(uint32_t i, V3& o, V3& d, float& time, float& minT, bool& has, HitOut& h) const {
-        if (i != lane) { L.bad_item = 1; return 0; }
-        if (L.req != OREQ_CLOSEST) return 0;
-        o = L.o; d = L.d; time = L.time;
-        minT = RT_FLT_MAX;
+    uint32_t* ps;                // this wave's slot 0 of field 0
+    size_t n_slots;              // words between fields
+    __device__ __forceinline__ uint32_t& f(uint32_t field, uint32_t i) const { return ps[(size_t)field * n_slots + i]; }
+    __device__ __forceinline__ float ff(uint32_t field, uint32_t i) const { return __uint_as_float(ps[(size_t)field * n_slots + i]); }
+    __device__ __forceinline__ uint32_t first_blocks() const { return (uint32_t)RT_ORDERED_SLOTS; }
+    __device__ __forceinline__ uint32_t first_count() const { return 64u * RT_ORDERED_SLOTS; }
+    __device__ __forceinline__ int load(uint32_t i, V3& o, V3& d, float& time, float& minT, bool& has, HitOut& h, bool& any) const {
+        const uint32_t req = f(PS_REQ, i);
+        if (req == OREQ_NONE) return 0;
+        o = mk(ff(PS_OX, i), ff(PS_OY, i), ff(PS_OZ, i));
+        d = mk(ff(PS_DX, i), ff(PS_DY, i), ff(PS_DZ, i));
+        time = ff(PS_TIME, i);
         has = false;
         h.kind_index = 0xFFFFFFFFu; h.tri = 0; h.beta = 0.f; h.gamma = 0.f;
-        for (uint32_t k = 0; k < S.n_planes; k++) {   // raytracer.cpp:423-435
+        if (req == OREQ_CLOSEST) {
+            any = false;
+            minT = RT_FLT_MAX;
+            for (uint32_t k = 0; k < S.n_planes; k++) {   // raytracer.cpp:423-435
+                float t;
+                if (plane_test(o, d, S.planes[k], minT, t)) { minT = t; has = true; h.kind_index = (RT_KIND_PLANE << 28) | k; }
+            }
+            return 2;
+        }
+        any = true;
+        minT = ff(PS_DIST, i);
+        for (uint32_t k = 0; k < S.n_planes; k++) {       // raytracer.cpp:1022-1028
             float t;
-            if (plane_test(o, d, S.planes[k], minT, t)) { minT = t; has = true; h.kind_index = (RT_KIND_PLANE << 28) | k; }
+            if (plane_test(o, d, S.planes[k], minT, t)) { f(PS_HAS, i) = 1u; f(PS_REQ, i) = OREQ_NONE; return 1; }
         }
         return 2;
     }
-    __device__ __forceinline__ void store(uint32_t, bool has, const HitOut& h, float minT) const {
-        L.has = has; L.t = minT; L.kind_index = has ? h.kind_index : 0xFFFFFFFFu; L.tri = h.tri; L.beta = h.beta; L.gamma = h.gamma;
-        L.req = OREQ_NONE;
-    }
-};
-struct LaneShadowIO {
-    const DScene& S;
-    LaneTrace& L;
-    uint32_t lane;
-    __device__ __forceinline__ int load(uint32_t i, V3& o, V3& d, float& time, float& minT, bool& has, HitOut&) const {
-        if (i != lane) { L.bad_item = 1; return 0; }
-        if (L.req != OREQ_ANYHIT) return 0;
-        o = L.o; d = L.d; time = L.time;
-        minT = L.dist;
-        has = false;
-        for (uint32_t k = 0; k < S.n_planes; k++) {   // raytracer.cpp:1022-1028
-            float t;
-            if (plane_test(o, d, S.planes[k], minT, t)) { L.has = true; L.req = OREQ_NONE; return 1; }
-        }
-        return 2;
-    }
-    __device__ __forceinline__ void store(uint32_t, bool shadow, const HitOut&, float) const { L.has = shadow; L.req = OREQ_NONE; }
-};
-
-// Both kinds in one trace loop (trace_persistent MODE 2): the lane's request says which its ray is.
-struct LaneMixedIO {
-    const DScene& S;
-    LaneTrace& L;
-    uint32_t lane;
-    __device__ __forceinline__ int load(uint32_t i, V3& o, V3& d, float& time, float& minT, bool& has, HitOut& h, bool& any) const {
-        if (i != lane) { L.bad_item = 1; return 0; }
-        if (L.req == OREQ_CLOSEST) { any = false; return LaneClosestIO{S, L, lane}.load(i, o, d, time, minT, has, h); }
-        if (L.req == OREQ_ANYHIT) { any = true; return LaneShadowIO{S, L, lane}.load(i, o, d, time, minT, has, h); }
-        return 0;
-    }
-    __device__ __forceinline__ uint32_t first_blocks() const { return 1u; }     // the 64 lanes' requests, item = lane
-    __device__ __forceinline__ uint32_t first_count() const { return 64u; }
     __device__ __forceinline__ void store(uint32_t i, bool verdict, const HitOut& h, float minT) const {
-        if (L.req == OREQ_ANYHIT) LaneShadowIO{S, L, lane}.store(i, verdict, h, minT);
-        else LaneClosestIO{S, L, lane}.store(i, verdict, h, minT);
+        if (f(PS_REQ, i) == OREQ_ANYHIT) {
+            f(PS_HAS, i) = verdict ? 1u : 0u;
+        } else {
+            f(PS_HAS, i) = verdict ? 1u : 0u;
+            f(PS_T, i) = __float_as_uint(minT);
+            f(PS_KIND, i) = verdict ? h.kind_index : 0xFFFFFFFFu;
+            f(PS_TRI, i) = h.tri;
+            f(PS_BETA, i) = __float_as_uint(h.beta);
+            f(PS_GAMMA, i) = __float_as_uint(h.gamma);
+        }
+        f(PS_REQ, i) = OREQ_NONE;
     }
 };
 
@@ -134,8 +146,9 @@ struct OrderedArgs {
     ChunkGeom g;
     const DAreaLight* area_lights;
     uint32_t n_area_lights;
-    uint32_t* mt_scratch;        // [624 + N][threads]
-    float* frames;               // [max_depth + 1][OF_COUNT][threads]
+    uint32_t* mt_scratch;        // [624 + N][slots]
+    float* frames;               // [max_depth + 1][OF_COUNT][slots]
+    uint32_t* pstate;            // [PS_COUNT][slots]
     float inv_n;
     uint8_t* rgb;
     size_t row_stride;
@@ -156,61 +169,113 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
     TraceStatsAcc acc = {};
     st.acc = &acc;
 #endif
-    const size_t n_threads = (size_t)gridDim.x * blockDim.x;
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr uint32_t K = RT_ORDERED_SLOTS;
+    const size_t n_slots = (size_t)gridDim.x * blockDim.x * K;
+    const size_t wave_base = ((size_t)blockIdx.x * (blockDim.x / 64) + ww.wave) * (64u * K);   // this wave's slot 0
     const int N = A.cam.num_samples, sps = A.cam.sps;
     const float fs = (float)sps;
     const float eps = S.shadow_eps;
-    MtGlobal gen;
-    gen.mt = A.mt_scratch + tid;
-    gen.stride = n_threads;
-    gen.idx = 624;
-    uint32_t* perm = A.mt_scratch + 624 * n_threads + tid;
-    float* fr = A.frames + tid;
-#define OFR(depth, field) fr[((size_t)(depth) * OF_COUNT + (field)) * n_threads]
-#define OFR_U(depth, field) (reinterpret_cast<uint32_t*>(fr)[((size_t)(depth) * OF_COUNT + (field)) * n_threads])
+    uint32_t* ps_wave = A.pstate + wave_base;
+    SlotMixedIO io{S, ps_wave, n_slots};
 
     unsigned long long n_primary = 0, n_secondary = 0, n_shadow = 0;   // per lane
-    LaneTrace L;
-    L.req = OREQ_NONE; L.bad_item = 0; L.has = false; L.t = 0.f; L.kind_index = 0xFFFFFFFFu; L.tri = 0; L.beta = L.gamma = 0.f;
-    L.o = L.d = mk(0, 0, 0); L.time = 0.f; L.dist = 0.f;
+    bool drained = false;        // wave-uniform: the chunk's pixel cursor has passed the last pixel
+    for (uint32_t k = 0; k < K; k++) io.f(PS_IDX, k * 64u + ww.lane) = RT_SLOT_EMPTY;
 
-    // every wave walks the 256-pixel groups of the chunk with a grid stride; all 64 lanes stay in the loop
-    const uint32_t n_groups = (A.g.n_idx + blockDim.x - 1) / blockDim.x;
-    for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
-        const uint32_t idx = group * blockDim.x + threadIdx.x;
-        int px = 0, py = 0;
-        bool done = !(idx < A.g.n_idx && idx_to_pixel(A.g, idx, px, py));
-        int s = 0, depth = 0;
-        V3 acc_color = mk(0.0f, 0.0f, 0.0f);
-        V3 ret = mk(0, 0, 0);
-        bool ret_pending = false, start_sample = !done;
-        uint32_t hit_w0 = 0xFFFFFFFFu, hit_tri = 0;
-        if (!done) {
-            gen.seed((uint32_t)(py * A.cam.image_w + px));
-            for (int k = 0; k < N; k++) perm[(size_t)k * n_threads] = (uint32_t)k;
-            int i = 1;   // std::shuffle, bits/stl_algo.h (pair path), as k_raygen_multi
-            if ((N % 2) == 0) {
-                uint32_t dpos = gen.lemire(2);
-                uint32_t a = perm[(size_t)i * n_threads], b = perm[(size_t)dpos * n_threads];
-                perm[(size_t)i * n_threads] = b; perm[(size_t)dpos * n_threads] = a;
-                i++;
-            }
-            while (i < N) {
-                uint32_t swap_range = (uint32_t)i + 1, b1 = swap_range + 1;
-                uint32_t x = gen.lemire(swap_range * b1);
-                uint32_t p0 = x / b1, p1 = x % b1;
-                uint32_t a = perm[(size_t)i * n_threads], b = perm[(size_t)p0 * n_threads];
-                perm[(size_t)i * n_threads] = b; perm[(size_t)p0 * n_threads] = a;
-                i++;
-                a = perm[(size_t)i * n_threads]; b = perm[(size_t)p1 * n_threads];
-                perm[(size_t)i * n_threads] = b; perm[(size_t)p1 * n_threads] = a;
-                i++;
-            }
-        }
+#ifdef RT_ORDERED_TIMES
+    unsigned long long tk_shade = 0, tk_trace = 0, tk_rounds = 0, tk_t0 = (unsigned long long)wall_clock64(), tk_tw = 0, tk_init = 0, n_tw = 0;
+#endif
+    for (;;) {
+#ifdef RT_ORDERED_TIMES
+        const unsigned long long tk_a = (unsigned long long)wall_clock64();
+#endif
+        bool any_request = false, any_pixel = false;     // per lane, over its slots
+#pragma unroll 1
+        for (uint32_t k = 0; k < K; k++) {
+            const uint32_t slot = k * 64u + ww.lane;      // item of this wave
+            const size_t gs = wave_base + slot;
+#define PSF(field) ps_wave[(size_t)(field) * n_slots + slot]
+            MtGlobal gen;
+            gen.mt = A.mt_scratch + gs;
+            gen.stride = n_slots;
+            uint32_t* perm = A.mt_scratch + 624 * n_slots + gs;
+            float* fr = A.frames + gs;
+#define OFR(depth, field) fr[((size_t)(depth) * OF_COUNT + (field)) * n_slots]
+#define OFR_U(depth, field) (reinterpret_cast<uint32_t*>(fr)[((size_t)(depth) * OF_COUNT + (field)) * n_slots])
 
-        for (;;) {
-            // ---- per lane: run ApplyShading forward until it needs a ray traced (or the pixel is finished)
+            uint32_t idx = PSF(PS_IDX);
+            int px = 0, py = 0;
+            int s = 0, depth = 0;
+            V3 acc_color = mk(0.0f, 0.0f, 0.0f), ret = mk(0, 0, 0);
+            bool ret_pending = false, start_sample = false;
+            uint32_t hit_w0 = 0xFFFFFFFFu, hit_tri = 0;
+            LaneTrace L;
+            L.req = OREQ_NONE; L.has = false; L.t = 0.f; L.kind_index = 0xFFFFFFFFu; L.tri = 0; L.beta = L.gamma = 0.f;
+            L.o = L.d = mk(0, 0, 0); L.time = 0.f; L.dist = 0.f;
+            gen.idx = 624;
+
+            // ---- an empty slot takes the next pixel of the chunk (one atomic per wave)
+            if (!drained) {
+                const uint64_t empty = __ballot(idx == RT_SLOT_EMPTY);
+                if (empty != 0) {
+                    uint32_t base = 0;
+                    if (ww.lane == 0) base = atomicAdd(&ctl->cursor_closest[0], (uint32_t)__popcll(empty));
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (base + (uint32_t)__popcll(empty) >= A.g.n_idx) drained = true;
+                    if (idx == RT_SLOT_EMPTY) {
+                        const uint32_t cand_idx = base + (uint32_t)__popcll(empty & ((1ull << ww.lane) - 1ull));
+                        if (cand_idx < A.g.n_idx && idx_to_pixel(A.g, cand_idx, px, py)) {
+                            idx = cand_idx;
+#ifdef RT_ORDERED_TIMES
+                            const unsigned long long ti_a = (unsigned long long)wall_clock64();
+#endif
+                            gen.seed((uint32_t)(py * A.cam.image_w + px));
+                            for (int q = 0; q < N; q++) perm[(size_t)q * n_slots] = (uint32_t)q;
+                            int i = 1;   // std::shuffle, bits/stl_algo.h (pair path), as k_raygen_multi
+                            if ((N % 2) == 0) {
+                                uint32_t dpos = gen.lemire(2);
+                                uint32_t a = perm[(size_t)i * n_slots], b = perm[(size_t)dpos * n_slots];
+                                perm[(size_t)i * n_slots] = b; perm[(size_t)dpos * n_slots] = a;
+                                i++;
+                            }
+                            while (i < N) {
+                                uint32_t swap_range = (uint32_t)i + 1, b1 = swap_range + 1;
+                                uint32_t x = gen.lemire(swap_range * b1);
+                                uint32_t p0 = x / b1, p1 = x % b1;
+                                uint32_t a = perm[(size_t)i * n_slots], b = perm[(size_t)p0 * n_slots];
+                                perm[(size_t)i * n_slots] = b; perm[(size_t)p0 * n_slots] = a;
+                                i++;
+                                a = perm[(size_t)i * n_slots]; b = perm[(size_t)p1 * n_slots];
+                                perm[(size_t)i * n_slots] = b; perm[(size_t)p1 * n_slots] = a;
+                                i++;
+                            }
+                            start_sample = true;
+#ifdef RT_ORDERED_TIMES
+                            tk_init += (unsigned long long)wall_clock64() - ti_a;
+#endif
+                        }
+                    } else {
+                        (void)idx_to_pixel(A.g, idx, px, py);
+                    }
+                }
+            }
+            bool done = idx == RT_SLOT_EMPTY;
+            if (!done && !start_sample) {
+                // ---- the slot's pixel is under way: its place in the loop, and the answer to its request
+                (void)idx_to_pixel(A.g, idx, px, py);
+                const uint32_t fl = PSF(PS_FLAGS);
+                ret_pending = (fl & 1u) != 0;
+                s = (int)PSF(PS_S); depth = (int)PSF(PS_DEPTH);
+                acc_color = mk(__uint_as_float(PSF(PS_ACC_R)), __uint_as_float(PSF(PS_ACC_G)), __uint_as_float(PSF(PS_ACC_B)));
+                ret = mk(__uint_as_float(PSF(PS_RET_R)), __uint_as_float(PSF(PS_RET_G)), __uint_as_float(PSF(PS_RET_B)));
+                hit_w0 = PSF(PS_HIT_W0); hit_tri = PSF(PS_HIT_TRI);
+                gen.idx = PSF(PS_GEN_IDX);
+                L.time = __uint_as_float(PSF(PS_TIME));
+                L.has = PSF(PS_HAS) != 0u; L.t = __uint_as_float(PSF(PS_T)); L.kind_index = PSF(PS_KIND); L.tri = PSF(PS_TRI);
+                L.beta = __uint_as_float(PSF(PS_BETA)); L.gamma = __uint_as_float(PSF(PS_GAMMA));
+            }
+
+            // ---- run ApplyShading forward until it needs a ray traced (or the pixel is finished)
             if (!done) {
                 for (;;) {
                     if (start_sample) {            // raytracer.cpp:56-74
@@ -218,7 +283,7 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
                         const int sx = s % sps, sy = s / sps;
                         const float jx = (sx + gen.uniform()) / fs;
                         const float jy = (sy + gen.uniform()) / fs;
-                        const int ai = (int)perm[(size_t)s * n_threads];
+                        const int ai = (int)perm[(size_t)s * n_slots];
                         const int ax = ai % sps, ay = ai / sps;
                         const float au = (ax + gen.uniform()) / fs;
                         const float av = (ay + gen.uniform()) / fs;
@@ -254,6 +319,7 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
                             ho[1] = (hit_w0 != 0xFFFFFFFFu && (hit_w0 >> 28) == RT_KIND_MESH) ? A.tri_shade[hit_tri].face : (hit_w0 == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u);
                         }
                         done = true;
+                        idx = RT_SLOT_EMPTY;       // (the slot takes its next pixel in the next round)
                         break;
                     }
 
@@ -447,38 +513,50 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
                     if (L.req != OREQ_NONE) break;
                 }
             }
-            if (!__any(!done)) break;
-
-            // ---- the wave traces what its lanes asked for
-#ifdef RT_ORDERED_TWO_LOOPS
-            if (__any(L.req == OREQ_CLOSEST)) {
-                if (ww.lane == 0) s_cursor[ww.wave] = 0;
-                LaneClosestIO io{S, L, ww.lane};
-                unsigned long long traced = 0;
-                trace_persistent<0, false, NEAR>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
+            // ---- the slot's state goes back to memory
+            PSF(PS_IDX) = idx;
+            if (!done) {
+                PSF(PS_FLAGS) = ret_pending ? 1u : 0u;
+                PSF(PS_S) = (uint32_t)s; PSF(PS_DEPTH) = (uint32_t)depth;
+                PSF(PS_ACC_R) = __float_as_uint(acc_color.x); PSF(PS_ACC_G) = __float_as_uint(acc_color.y); PSF(PS_ACC_B) = __float_as_uint(acc_color.z);
+                PSF(PS_RET_R) = __float_as_uint(ret.x); PSF(PS_RET_G) = __float_as_uint(ret.y); PSF(PS_RET_B) = __float_as_uint(ret.z);
+                PSF(PS_HIT_W0) = hit_w0; PSF(PS_HIT_TRI) = hit_tri;
+                PSF(PS_GEN_IDX) = gen.idx;
+                PSF(PS_TIME) = __float_as_uint(L.time);
+                PSF(PS_OX) = __float_as_uint(L.o.x); PSF(PS_OY) = __float_as_uint(L.o.y); PSF(PS_OZ) = __float_as_uint(L.o.z);
+                PSF(PS_DX) = __float_as_uint(L.d.x); PSF(PS_DY) = __float_as_uint(L.d.y); PSF(PS_DZ) = __float_as_uint(L.d.z);
+                PSF(PS_DIST) = __float_as_uint(L.dist);
+                any_pixel = true;
             }
-            if (__any(L.req == OREQ_ANYHIT)) {
-                if (ww.lane == 0) s_cursor[ww.wave] = 0;
-                LaneShadowIO io{S, L, ww.lane};
-                unsigned long long traced = 0;
-                trace_persistent<1, false, false>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
-            }
-#else
-            // closest-hit and any-hit requests share one loop: all lanes with a request are busy in it together,
-            // and the kernel holds one copy of the traversal instead of two
-            if (__any(L.req != OREQ_NONE)) {
-                if (ww.lane == 0) s_cursor[ww.wave] = 0;
-                LaneMixedIO io{S, L, ww.lane};
-                unsigned long long traced = 0;
-                trace_persistent<2, false, NEAR>(S, io, 0u, 64u, &s_cursor[ww.wave], st, traced);
-            }
-#endif
-        }
-    }
+            PSF(PS_REQ) = done ? (uint32_t)OREQ_NONE : (uint32_t)L.req;
+            any_request = any_request || (!done && L.req != OREQ_NONE);
 #undef OFR
 #undef OFR_U
+#undef PSF
+        }
+        // a slot that became empty in this round takes a new pixel in the next one, unless the chunk has none left
+        if (!__any(any_pixel) && drained) break;
+#ifdef RT_ORDERED_TIMES
+        const unsigned long long tk_b = (unsigned long long)wall_clock64();
+#endif
+
+        // ---- the wave traces what its slots asked for: closest-hit and any-hit requests in one loop, 64 * SLOTS items
+        // behind a cursor, so lanes whose ray is finished take the next request and long rays give subtrees away
+        if (__any(any_request)) {
+            if (ww.lane == 0) s_cursor[ww.wave] = 0;
+            unsigned long long traced = 0;
+            trace_persistent<2, false, NEAR>(S, io, 0u, 64u * K, &s_cursor[ww.wave], st, traced);
+        }
+#ifdef RT_ORDERED_TIMES
+        { const unsigned long long tk_c = (unsigned long long)wall_clock64(); tk_shade += tk_b - tk_a; tk_trace += tk_c - tk_b; tk_rounds++; }
+#endif
+    }
+#ifdef RT_ORDERED_TIMES
+    if (ww.lane == 0 && (((blockIdx.x % 97) == 0 && ww.wave == 0) || ((unsigned long long)wall_clock64() - tk_t0) > 26000000ull))
+        printf("[ordered] block %d: life %.0f us, %llu rounds: shade %.0f us (%.1f per round), trace %.0f us (%.1f per round) | lane 0: pixel init %.0f us\n", (int)blockIdx.x,
+               ((unsigned long long)wall_clock64() - tk_t0) * 0.01, tk_rounds, tk_shade * 0.01, tk_shade * 0.01 / tk_rounds, tk_trace * 0.01, tk_trace * 0.01 / tk_rounds, tk_init * 0.01);
+#endif
     if (st.overflow) atomicOr(&ctl->overflow, (st.overflow & 48u) | ((st.overflow & ~48u) ? 4u : 0u));
-    if (L.bad_item) atomicOr(&ctl->overflow, 8u);
 #ifdef RT_TRACE_STATS
     atomicAdd(&ctl->dbg[0], acc.wave_node_steps); atomicAdd(&ctl->dbg[1], acc.lane_node_steps);
     atomicAdd(&ctl->dbg[2], acc.wave_tri_steps); atomicAdd(&ctl->dbg[3], acc.lane_tri_steps);
