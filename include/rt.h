@@ -282,8 +282,13 @@ int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out);
  * and rebuilt by the library with a binned surface-area heuristic over the same faces; the scene is then always
  * traced as with RT_FLAG_NEAR_FIRST, ties going to the triangle that comes first in the CALLER's leaf order.
  * Frames equal the reference's wherever its box culls agree with its triangle tests; hit ids and
- * colours are tested to the north_star's tolerance, not to byte-exactness.  flags == 0 is rt_upload_scene. */
-enum { RT_UPLOAD_REBUILD_MESH_BVH = 1u };
+ * colours are tested to the north_star's tolerance, not to byte-exactness.  flags == 0 is rt_upload_scene.
+ *
+ * RT_UPLOAD_REBUILD_ON_DEVICE (with RT_UPLOAD_REBUILD_MESH_BVH): the rebuild runs on the GPU as a linear BVH (Morton
+ * sort + Karras' radix tree, rt_lbvh.h) instead of the host's binned SAH: an upload of a 1 M-triangle scene in tens of
+ * milliseconds instead of ~0.2 s, for trees that trace somewhat slower than the SAH ones.  Same
+ * tolerance, same tie rule. */
+enum { RT_UPLOAD_REBUILD_MESH_BVH = 1u, RT_UPLOAD_REBUILD_ON_DEVICE = 2u };
 int rt_upload_scene_ex(int device, const rt_scene_desc* scene, uint32_t flags, rt_scene** out);
 
 /* Next frame of an animation whose meshes do not change: re-derive everything

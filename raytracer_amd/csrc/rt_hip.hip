@@ -23,6 +23,7 @@
 #include "rt_mega.h"
 #include "rt_upload.h"
 #include "rt_rebuild.h"
+#include "rt_lbvh.h"
 
 namespace {
 
@@ -749,8 +750,14 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s, uint32_t upload_fla
         uint32_t max_leaf = 4;
         if (const char* e = getenv("RT_REBUILD_MAX_LEAF")) max_leaf = (uint32_t)std::max(2, std::min(30, atoi(e)));
         rt_rebuild::MeshLevel R;
-        rt_rebuild::rebuild(s, max_leaf, R);
-        pc.lap("SAH rebuild (host)");
+        if (upload_flags & RT_UPLOAD_REBUILD_ON_DEVICE) {
+            const char* err = nullptr;
+            if (!rt_lbvh::rebuild(s, max_leaf, R, err)) return fail(RT_ERR_HIP, "LBVH rebuild: %s", err ? err : "?");
+            pc.lap("LBVH rebuild (device)");
+        } else {
+            rt_rebuild::rebuild(s, max_leaf, R);
+            pc.lap("SAH rebuild (host)");
+        }
         rt_scene_desc s2 = *s;
         s2.mesh_nodes = R.nodes.data(); s2.n_mesh_nodes = (uint32_t)R.nodes.size();
         s2.mesh_bvhs = R.bvhs.data();
@@ -1290,7 +1297,8 @@ int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out) { re
 
 int rt_upload_scene_ex(int device, const rt_scene_desc* scene, uint32_t upload_flags, rt_scene** out) {
     if (!out) return fail(RT_ERR_INVALID, "out is NULL");
-    if (upload_flags & ~(uint32_t)RT_UPLOAD_REBUILD_MESH_BVH) return fail(RT_ERR_INVALID, "unknown upload flag");
+    if (upload_flags & ~(uint32_t)(RT_UPLOAD_REBUILD_MESH_BVH | RT_UPLOAD_REBUILD_ON_DEVICE)) return fail(RT_ERR_INVALID, "unknown upload flag");
+    if ((upload_flags & RT_UPLOAD_REBUILD_ON_DEVICE) && !(upload_flags & RT_UPLOAD_REBUILD_MESH_BVH)) return fail(RT_ERR_INVALID, "RT_UPLOAD_REBUILD_ON_DEVICE goes with RT_UPLOAD_REBUILD_MESH_BVH");
     *out = nullptr;
     // the description is checked first (host work only), so a malformed scene is reported as such on any box
     PhaseClock pc;

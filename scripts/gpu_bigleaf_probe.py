@@ -19,9 +19,9 @@ s.meshes = [dict(verts=np.concatenate([verts, ground]), faces=np.concatenate([fa
 hs = s.build()
 cam = hs.camera(0)
 out = {}
-for mode in ("exact", "rebuilt"):
+for mode in ("exact", "rebuilt", "device"):
     t = time.perf_counter()
-    ds = rt.DeviceScene(hs, 0, rebuild_mesh_bvh=(mode == "rebuilt"))
+    ds = rt.DeviceScene(hs, 0, rebuild_mesh_bvh=(True if mode == "rebuilt" else ("device" if mode == "device" else False)))
     up = time.perf_counter() - t
     ds.set_option(rt.RT_OPT_FLAGS, rt.RT_FLAG_TIMING)
     best = None

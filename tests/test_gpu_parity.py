@@ -611,6 +611,47 @@ def test_rebuilt_mesh_bvh_mode_vs_exact_mode_and_scene_update(rt):
 
 
 @pytest.mark.gpu
+def test_mesh_bvhs_rebuilt_on_the_device_meet_the_tolerance(rt):
+    """RT_UPLOAD_REBUILD_MESH_BVH | RT_UPLOAD_REBUILD_ON_DEVICE (SURVEY 8f-3 on the GPU, rt_lbvh.h): linear BVHs built by
+    Morton sort + Karras' radix tree, emitted in the reference's node format.  Same bar as the host rebuild: the
+    north_star's tolerance against the reference's own renders on mesh scenes of every kind (many overlapping meshes, a
+    scanned 100 000-face mesh, instances under a one-leaf top level, inline meshes, a binary PLY with a rough material),
+    and against the exact mode on the bench's scene family; rt_update_scene keeps the device-built trees."""
+    for name in ("hw1_cornellbox_recursive", "hw2_two_berserkers", "hw2_davids_camera_000", "hw2_grass_desert", "hw2_metal_glass_plates",
+                 "hw3_chessboard_arealight", "hw3_tap_0100"):
+        hs = util.golden_scene(name)
+        cam = hs.camera(0)
+        ds = rt.DeviceScene(hs, 0, rebuild_mesh_bvh="device")
+        tile = util.golden_tile(name) or (0, 0, cam.image_width, cam.image_height)
+        rgb, hits = ds.render(cam, *tile, want_hits=True)
+        ds.close()
+        st = util.image_stats(rgb, util.golden_image(name))
+        ok = util.hit_ids_match(hits, util.golden_hits(name), hs)
+        print(f"device-rebuilt {name}: hit ids {ok.mean():.6f} exact {st['exact']:.6f} within1 {st['within1']:.6f}")
+        assert ok.mean() >= 0.9999, (name, ok.mean())
+        assert st["within1"] >= 0.999, (name, st)
+    for spec in (rt.scenes.mesh_scene(grid=256, width=960, height=540), rt.scenes.instanced_scene(grid=128, width=640, height=360),
+                 rt.scenes.deep_chain_scene()):
+        hs = spec.build()
+        cam = hs.camera(0)
+        ds = rt.DeviceScene(hs, 0)
+        s0, s1 = rt.Stats(), rt.Stats()
+        rgb0, hits0 = ds.render(cam, want_hits=True, stats=s0)
+        ds.close()
+        ds = rt.DeviceScene(hs, 0, rebuild_mesh_bvh="device")
+        rgb1, hits1 = ds.render(cam, want_hits=True, stats=s1)
+        ds.update(hs, verify_meshes=True)
+        rgb2, hits2 = ds.render(cam, want_hits=True)
+        ds.close()
+        same = (hits0.reshape(-1, 2) == hits1.reshape(-1, 2)).all(axis=1)
+        d = np.abs(rgb0.astype(np.int16) - rgb1.astype(np.int16)).max(axis=-1)
+        print(f"device-rebuilt {spec.name}: hit ids {same.mean():.6f} exact {(d == 0).mean():.6f}")
+        assert same.mean() >= 0.9999 and (d <= 1).mean() >= 0.999
+        assert s0.rays_primary == s1.rays_primary
+        assert (rgb2 == rgb1).all() and (hits2 == hits1).all()
+
+
+@pytest.mark.gpu
 def test_unsplittable_big_leaves_vs_oracle_in_all_modes(rt):
     """The dragon_new pathology (blog/hw2/episode2.md:240-248): SubdivideMesh gives up when every centroid falls on
     one side of the midpoint (raytracer.cpp:317), leaving a leaf of hundreds of triangles.  Two decks of stacked
@@ -673,7 +714,10 @@ def test_unsplittable_big_leaves_vs_oracle_in_all_modes(rt):
     ds = rt.DeviceScene(hs, 0, rebuild_mesh_bvh=True)
     rgb2, hits2 = ds.render(cam, want_hits=True)
     ds.close()
-    for name, r, h in (("near-first", rgb1, hits1), ("rebuilt", rgb2, hits2)):
+    ds = rt.DeviceScene(hs, 0, rebuild_mesh_bvh="device")
+    rgb3, hits3 = ds.render(cam, want_hits=True)
+    ds.close()
+    for name, r, h in (("near-first", rgb1, hits1), ("rebuilt", rgb2, hits2), ("rebuilt on the device", rgb3, hits3)):
         same = (h.reshape(-1, 2) == hits.reshape(-1, 2)).all(axis=1)
         dd = np.abs(r.astype(np.int16) - rgb.astype(np.int16)).max(axis=-1)
         print(f"big leaves, {name}: hit ids {same.mean():.6f} exact {(dd == 0).mean():.6f}")
