@@ -761,14 +761,16 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     __hip_atomic_store(cp + 1, __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(cp + 2, __float_as_uint(te), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (t >= te) tmax = t;
-            } else {
-                tmax = t;
-                mesh_found = true;
-                mesh_tri = ti;
-                mesh_beta = bb;
-                mesh_gamma = gg;
             }
+            // (written as selects on purpose: with `tmax = t` under two different conditions the optimiser turns the two
+            // stores into one store through a selected ADDRESS, and tmax / mesh_* then live in scratch memory for the
+            // whole kernel — a scratch round trip per triangle step)
+            const bool mine = !helper;
+            tmax = (mine || t >= te) ? t : tmax;
+            mesh_found = mesh_found || mine;
+            mesh_tri = mine ? ti : mesh_tri;
+            mesh_beta = mine ? bb : mesh_beta;
+            mesh_gamma = mine ? gg : mesh_gamma;
             if (RT_ISANY) {
                 // Untransformed mesh: worldT == t < testMinT == minT, so the
                 // reference's verdict is already known.
