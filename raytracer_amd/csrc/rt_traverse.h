@@ -89,12 +89,16 @@
 #ifndef RT_STRIP_ANY
 #define RT_STRIP_ANY 64          // any-hit: 64 consecutive shadow slots are rays of neighbouring pixels towards one light (k_shade): keep blocks whole (8 / 16 / 32: 20 / 11 / 4 % slower)
 #endif
-// node phase exit: at most EXIT_FEW lanes still walking and at least EXIT_WAIT lanes waiting with queued leaves
+// node phase exit: at most EXIT_FEW lanes still walking and at least EXIT_WAIT lanes waiting, either with queued leaves or
+// (RT_WAIT_COUNTS_TRANSITIONS) for the round's transition: a finished ray to be retired, an instance to be entered or left.
+// An owner parked until its helpers report is not waiting for the wave and is not counted, or the node phase would end
+// before the helpers in the same wave took a step. 24/8 without transitions -> 16/16 with: mesh1m +3.5 %, inst10 +4 %
+// (profiles/r02/l_exit_rule_sweep.txt)
 #ifndef RT_EXIT_FEW
-#define RT_EXIT_FEW 24
+#define RT_EXIT_FEW 16
 #endif
 #ifndef RT_EXIT_WAIT
-#define RT_EXIT_WAIT 8
+#define RT_EXIT_WAIT 16
 #endif
 #ifndef RT_EXIT_FEW_ANY
 #define RT_EXIT_FEW_ANY 20
@@ -107,6 +111,9 @@
 #endif
 #ifndef RT_DONATE_PASSES
 #define RT_DONATE_PASSES 4       // stack entries a busy lane may post per round (helpers included, so a subtree fans out)
+#endif
+#ifndef RT_WAIT_COUNTS_TRANSITIONS
+#define RT_WAIT_COUNTS_TRANSITIONS 1
 #endif
 #ifndef RT_TAIL_STEPS
 #define RT_TAIL_STEPS 16         // node steps per round once the cursor is drained: the wave then looks at the task board that often
@@ -650,7 +657,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 // leaves: the walkers keep their place and go on in the next node phase.  (A wave completes a
                 // step about every 1.3 us whatever the number of active lanes, so steps with few lanes cost
                 // as much as full ones.)
-                const uint32_t n_want = (uint32_t)__popcll(__ballot(want)), n_wait = (uint32_t)__popcll(__ballot(!want && qn != 0));
+                const uint32_t n_want = (uint32_t)__popcll(__ballot(want)), n_wait = (uint32_t)__popcll(__ballot(!want && (qn != 0 || (RT_WAIT_COUNTS_TRANSITIONS && alive && !donated))));
                 if (n_want == 0 || (n_want <= exit_few && n_wait >= exit_wait)) break;
                 // end game (subtrees are being donated): short node phases, so that posted subtrees are taken and
                 // new ones posted every few steps instead of once per ~30 — a long ray fans out over the idle lanes
