@@ -999,11 +999,11 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         // depth-first so that the draws come in the reference's order (rt_ordered.h).  One launch, grid-stride.
         const uint32_t n_idx = total_tiles * 64u;
         const int grid = (int)std::min<uint32_t>((uint32_t)sc->blocks_ordered, (n_idx + RT_ORDERED_BLOCK - 1) / RT_ORDERED_BLOCK);
-        // (a lane owns RT_ORDERED_SLOTS pixels at a time: generator, frame stack and loop state per slot)
-        const size_t threads = (size_t)std::max(grid, 1) * RT_ORDERED_BLOCK * RT_ORDERED_SLOTS;
+        // (a lane owns one pixel at a time — generator, frame stack, loop state — and RT_ORDERED_REQS request slots)
+        const size_t threads = (size_t)std::max(grid, 1) * RT_ORDERED_BLOCK;
         if ((rc = sc->b_mt.ensure(threads * (624 + (size_t)N) * 4))) return rc;
         if ((rc = sc->b_frames.ensure(threads * (size_t)(depth + 1) * OF_COUNT * 4))) return rc;
-        if ((rc = sc->b_pstate.ensure(threads * (size_t)PS_COUNT * 4))) return rc;
+        if ((rc = sc->b_pstate.ensure(threads * RT_ORDERED_REQS * (size_t)PS_COUNT * 4))) return rc;
         OrderedArgs A;
         A.cam = dc;
         A.g = ChunkGeom{x0, y0, w, h, tiles_per_row, 0u, n_idx, row_parts, row_part};

@@ -28,13 +28,12 @@ struct DAreaLight { float px, py, pz, nx, ny, nz, size, rx, ry, rz; };
 enum {
     OF_OX, OF_OY, OF_OZ, OF_DX, OF_DY, OF_DZ,     // the frame's ray
     OF_THIT, OF_NX, OF_NY, OF_NZ, OF_MAT,         // its hit: t, HitRecord::normal, material id
-    OF_STAGE, OF_LIGHT,                           // where ApplyShading stands
+    OF_STAGE, OF_LIGHT,                           // where ApplyShading stands; first light of the batch of tests in flight
     OF_CR, OF_CG, OF_CB,                          // `color` so far
     OF_RR, OF_RG, OF_RB,                          // reflectColor (dielectric, raytracer.cpp:1335)
-    OF_WX, OF_WY, OF_WZ, OF_DIST,                 // area light sample in flight: wi, dist_to_light
     OF_COUNT
 };
-enum { OS_TRACE = 0, OS_REFLECT_WAIT, OS_REFRACT_WAIT, OS_POINT, OS_AREA };
+enum { OS_TRACE = 0, OS_REFLECT_WAIT, OS_REFRACT_WAIT, OS_LIGHTS };
 enum { OREQ_NONE = 0, OREQ_CLOSEST = 1, OREQ_ANYHIT = 2 };
 
 // CreateOrthonormalBasis, raytracer.cpp:1522-1537
@@ -57,24 +56,32 @@ __device__ __forceinline__ V3 perturb_reflection(V3 r, float roughness, MtGlobal
     return normalize(rr);
 }
 
-// ---- pixel slots.  A lane owns RT_ORDERED_SLOTS pixels at a time (slot k of lane l of a wave = item k * 64 + l of that
-// wave); everything a pixel needs between two of its rays lives in global memory, one 4-byte field per slot, stored
-// [field][slot] so that the 64 lanes of a wave read and write neighbouring words: the pixel's place in the loop
-// below (PS_*), its frame stack (OF_*), its generator.  The REQUEST a pixel has posted and the ANSWER it gets back
-// are fields too, so any lane of the wave can trace any slot's ray: the traversal loop sees the wave's 64 * SLOTS
-// requests as one list of items with a cursor, refills idle lanes from it and hands subtrees of long rays to idle
-// lanes — with one pixel per lane (the first version) every trace call was as slow as the slowest of 64 rays.
-#ifndef RT_ORDERED_SLOTS
-#define RT_ORDERED_SLOTS 1
+// ---- pixel state and request slots.  Everything a pixel needs between two of its rays lives in global memory, one
+// 4-byte field per slot, stored [field][slot] so that the 64 lanes of a wave read and write neighbouring words: the
+// pixel's place in the loop below (PS_*), its frame stack (OF_*), its generator.  The REQUESTS a pixel has posted and
+// the ANSWERS it gets back are fields too, RT_ORDERED_REQS of them per lane (request r of lane l = item r * 64 + l of
+// the wave), so any lane of the wave can trace any request: the traversal loop sees the wave's 64 * REQS requests as
+// one list of items with a cursor and refills idle lanes from it.
+//
+// Why several requests per pixel: the rays of a pixel are sequential only where a result decides what is drawn or
+// traced next.  The light tests of one hit are not: InShadow towards each point light and the closest hit towards each
+// area-light sample (raytracer.cpp:1371-1433) only add to `color`, and the two draws per area light follow each other
+// with nothing drawn in between.  So a hit posts all its light tests at once (REQS at a time), the draws made in the
+// reference's order when they are posted, and the contributions are added in the reference's order when the answers
+// are back: the chain of rounds per hit is 1 + ceil(lights / REQS) instead of 1 + lights.
+#ifndef RT_ORDERED_REQS
+#define RT_ORDERED_REQS 2
 #endif
 enum {
-    PS_IDX,                                     // pixel index in the chunk; 0xFFFFFFFF: the slot is empty
+    // per pixel (request slot 0 of the lane holds them)
+    PS_IDX,                                     // pixel index in the chunk; 0xFFFFFFFF: the lane has no pixel
     PS_FLAGS,                                   // 1: ret_pending, 2: start_sample
     PS_S, PS_DEPTH,
     PS_ACC_R, PS_ACC_G, PS_ACC_B,
     PS_RET_R, PS_RET_G, PS_RET_B,
     PS_HIT_W0, PS_HIT_TRI,
     PS_GEN_IDX, PS_TIME,
+    // per request slot
     PS_REQ, PS_OX, PS_OY, PS_OZ, PS_DX, PS_DY, PS_DZ, PS_DIST,          // the request: OREQ_*, ray, InShadow's distance
     PS_HAS, PS_T, PS_KIND, PS_TRI, PS_BETA, PS_GAMMA,                   // the answer
     PS_COUNT
@@ -99,14 +106,14 @@ struct SlotMixedIO {
     size_t n_slots;              // words between fields
     __device__ __forceinline__ uint32_t& f(uint32_t field, uint32_t i) const { return ps[(size_t)field * n_slots + i]; }
     __device__ __forceinline__ float ff(uint32_t field, uint32_t i) const { return __uint_as_float(ps[(size_t)field * n_slots + i]); }
-    __device__ __forceinline__ uint32_t first_blocks() const { return (uint32_t)RT_ORDERED_SLOTS; }
-    __device__ __forceinline__ uint32_t first_count() const { return 64u * RT_ORDERED_SLOTS; }
+    __device__ __forceinline__ uint32_t first_blocks() const { return 1u; }      // the cursor hands out slot 0 of every lane first, then the other slots in order
+    __device__ __forceinline__ uint32_t first_count() const { return 64u; }
     __device__ __forceinline__ int load(uint32_t i, V3& o, V3& d, float& time, float& minT, bool& has, HitOut& h, bool& any) const {
         const uint32_t req = f(PS_REQ, i);
         if (req == OREQ_NONE) return 0;
         o = mk(ff(PS_OX, i), ff(PS_OY, i), ff(PS_OZ, i));
         d = mk(ff(PS_DX, i), ff(PS_DY, i), ff(PS_DZ, i));
-        time = ff(PS_TIME, i);
+        time = ff(PS_TIME, i & 63u);            // the pixel's (raytracer.cpp:69), kept with its lane
         has = false;
         h.kind_index = 0xFFFFFFFFu; h.tri = 0; h.beta = 0.f; h.gamma = 0.f;
         if (req == OREQ_CLOSEST) {
@@ -146,9 +153,9 @@ struct OrderedArgs {
     ChunkGeom g;
     const DAreaLight* area_lights;
     uint32_t n_area_lights;
-    uint32_t* mt_scratch;        // [624 + N][slots]
-    float* frames;               // [max_depth + 1][OF_COUNT][slots]
-    uint32_t* pstate;            // [PS_COUNT][slots]
+    uint32_t* mt_scratch;        // [624 + N][threads]
+    float* frames;               // [max_depth + 1][OF_COUNT][threads]
+    uint32_t* pstate;            // [PS_COUNT][threads * RT_ORDERED_REQS]
     float inv_n;
     uint8_t* rgb;
     size_t row_stride;
@@ -169,18 +176,23 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
     TraceStatsAcc acc = {};
     st.acc = &acc;
 #endif
-    constexpr uint32_t K = RT_ORDERED_SLOTS;
-    const size_t n_slots = (size_t)gridDim.x * blockDim.x * K;
-    const size_t wave_base = ((size_t)blockIdx.x * (blockDim.x / 64) + ww.wave) * (64u * K);   // this wave's slot 0
+    constexpr uint32_t K = RT_ORDERED_REQS;
+    const size_t n_pix = (size_t)gridDim.x * blockDim.x;            // words between the fields of generators and frames
+    const size_t n_slots = n_pix * K;                               // words between the fields of the pixel / request state
+    const size_t wave_index = (size_t)blockIdx.x * (blockDim.x / 64) + ww.wave;
+    const size_t wave_base = wave_index * (64u * K);                // this wave's request slot 0
+    const size_t gs = wave_index * 64u + ww.lane;                   // this lane's generator and frame stack
     const int N = A.cam.num_samples, sps = A.cam.sps;
     const float fs = (float)sps;
     const float eps = S.shadow_eps;
     uint32_t* ps_wave = A.pstate + wave_base;
     SlotMixedIO io{S, ps_wave, n_slots};
+    const uint32_t n_lights = S.n_point_lights + A.n_area_lights;
 
     unsigned long long n_primary = 0, n_secondary = 0, n_shadow = 0;   // per lane
     bool drained = false;        // wave-uniform: the chunk's pixel cursor has passed the last pixel
-    for (uint32_t k = 0; k < K; k++) io.f(PS_IDX, k * 64u + ww.lane) = RT_SLOT_EMPTY;
+    io.f(PS_IDX, ww.lane) = RT_SLOT_EMPTY;
+    for (uint32_t k = 0; k < K; k++) io.f(PS_REQ, k * 64u + ww.lane) = OREQ_NONE;
 
 #ifdef RT_ORDERED_TIMES
     unsigned long long tk_shade = 0, tk_trace = 0, tk_rounds = 0, tk_t0 = (unsigned long long)wall_clock64(), tk_tw = 0, tk_init = 0, n_tw = 0;
@@ -189,19 +201,19 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
 #ifdef RT_ORDERED_TIMES
         const unsigned long long tk_a = (unsigned long long)wall_clock64();
 #endif
-        bool any_request = false, any_pixel = false;     // per lane, over its slots
-#pragma unroll 1
-        for (uint32_t k = 0; k < K; k++) {
-            const uint32_t slot = k * 64u + ww.lane;      // item of this wave
-            const size_t gs = wave_base + slot;
+        bool any_request = false, any_pixel = false;     // per lane
+        {
+            const uint32_t slot = ww.lane;                // the lane's request slot 0: pixel state, and the one request of a ray that continues the path
 #define PSF(field) ps_wave[(size_t)(field) * n_slots + slot]
+#define PSQ(field, q) ps_wave[(size_t)(field) * n_slots + (q) * 64u + ww.lane]      // request slot q of this lane
             MtGlobal gen;
             gen.mt = A.mt_scratch + gs;
-            gen.stride = n_slots;
-            uint32_t* perm = A.mt_scratch + 624 * n_slots + gs;
+            gen.stride = n_pix;
+            uint32_t* perm = A.mt_scratch + 624 * n_pix + gs;
             float* fr = A.frames + gs;
-#define OFR(depth, field) fr[((size_t)(depth) * OF_COUNT + (field)) * n_slots]
-#define OFR_U(depth, field) (reinterpret_cast<uint32_t*>(fr)[((size_t)(depth) * OF_COUNT + (field)) * n_slots])
+#define OFR(depth, field) fr[((size_t)(depth) * OF_COUNT + (field)) * n_pix]
+#define OFR_U(depth, field) (reinterpret_cast<uint32_t*>(fr)[((size_t)(depth) * OF_COUNT + (field)) * n_pix])
+            bool lights_posted = false;                   // this round's requests are light tests, written to the slots directly
 
             uint32_t idx = PSF(PS_IDX);
             int px = 0, py = 0;
@@ -230,23 +242,23 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
                             const unsigned long long ti_a = (unsigned long long)wall_clock64();
 #endif
                             gen.seed((uint32_t)(py * A.cam.image_w + px));
-                            for (int q = 0; q < N; q++) perm[(size_t)q * n_slots] = (uint32_t)q;
+                            for (int q = 0; q < N; q++) perm[(size_t)q * n_pix] = (uint32_t)q;
                             int i = 1;   // std::shuffle, bits/stl_algo.h (pair path), as k_raygen_multi
                             if ((N % 2) == 0) {
                                 uint32_t dpos = gen.lemire(2);
-                                uint32_t a = perm[(size_t)i * n_slots], b = perm[(size_t)dpos * n_slots];
-                                perm[(size_t)i * n_slots] = b; perm[(size_t)dpos * n_slots] = a;
+                                uint32_t a = perm[(size_t)i * n_pix], b = perm[(size_t)dpos * n_pix];
+                                perm[(size_t)i * n_pix] = b; perm[(size_t)dpos * n_pix] = a;
                                 i++;
                             }
                             while (i < N) {
                                 uint32_t swap_range = (uint32_t)i + 1, b1 = swap_range + 1;
                                 uint32_t x = gen.lemire(swap_range * b1);
                                 uint32_t p0 = x / b1, p1 = x % b1;
-                                uint32_t a = perm[(size_t)i * n_slots], b = perm[(size_t)p0 * n_slots];
-                                perm[(size_t)i * n_slots] = b; perm[(size_t)p0 * n_slots] = a;
+                                uint32_t a = perm[(size_t)i * n_pix], b = perm[(size_t)p0 * n_pix];
+                                perm[(size_t)i * n_pix] = b; perm[(size_t)p0 * n_pix] = a;
                                 i++;
-                                a = perm[(size_t)i * n_slots]; b = perm[(size_t)p1 * n_slots];
-                                perm[(size_t)i * n_slots] = b; perm[(size_t)p1 * n_slots] = a;
+                                a = perm[(size_t)i * n_pix]; b = perm[(size_t)p1 * n_pix];
+                                perm[(size_t)i * n_pix] = b; perm[(size_t)p1 * n_pix] = a;
                                 i++;
                             }
                             start_sample = true;
@@ -283,7 +295,7 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
                         const int sx = s % sps, sy = s / sps;
                         const float jx = (sx + gen.uniform()) / fs;
                         const float jy = (sy + gen.uniform()) / fs;
-                        const int ai = (int)perm[(size_t)s * n_slots];
+                        const int ai = (int)perm[(size_t)s * n_pix];
                         const int ax = ai % sps, ay = ai / sps;
                         const float au = (ax + gen.uniform()) / fs;
                         const float av = (ay + gen.uniform()) / fs;
@@ -327,7 +339,7 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
                     const uint32_t stage = OFR_U(depth, OF_STAGE);
                     const V3 o = mk(OFR(depth, OF_OX), OFR(depth, OF_OY), OFR(depth, OF_OZ));
                     const V3 d = mk(OFR(depth, OF_DX), OFR(depth, OF_DY), OFR(depth, OF_DZ));
-                    bool to_lights = false, do_return = false, spawn = false, next_point = false, next_area = false;
+                    bool to_lights = false, do_return = false, spawn = false, post_lights = false;
                     bool shaded = false;           // the frame has a hit: c / mat / color below are valid
                     V3 color = mk(0, 0, 0);
                     V3 child_o = mk(0, 0, 0), child_d = mk(0, 0, 0);
@@ -406,84 +418,91 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
                         }
                         color = (color + reflectColor * c.Fr) + refractColor * (1.0f - c.Fr);
                         if (!c.entering) { ret = color; do_return = true; } else to_lights = true;
-                    } else if (stage == OS_POINT) {           // InShadow returned (:1371-1377)
+                    } else if (stage == OS_LIGHTS) {          // the answers of a batch of light tests, in the reference's order
                         light = OFR_U(depth, OF_LIGHT);
-                        if (!L.has) color = color + diffuse_specular(mat, S.point_lights[light], c.x, c.n_shading, c.w0);
-                        light++;
-                        next_point = true;
-                    } else if (stage == OS_AREA) {            // the closest hit towards the light sample returned (:1405-1411)
-                        light = OFR_U(depth, OF_LIGHT);
-                        const DAreaLight& al = A.area_lights[light];
-                        const V3 wi = mk(OFR(depth, OF_WX), OFR(depth, OF_WY), OFR(depth, OF_WZ));
-                        const float dist_to_light = OFR(depth, OF_DIST);
-                        bool in_sh = false;
-                        if (L.has) {
-                            const V3 so = c.x + c.n_shading * eps;
-                            const V3 sh_x = so + wi * L.t;
-                            const float dist_to_hit = vlen(sh_x - so);
-                            if (dist_to_hit < dist_to_light - eps) in_sh = true;
+                        const uint32_t nl = min((uint32_t)K, n_lights - light);
+                        for (uint32_t qq = 0; qq < nl; qq++, light++) {
+                            const uint32_t q = nl - 1u - qq;  // (slots in reverse, see where they are posted)
+                            const bool q_has = PSQ(PS_HAS, q) != 0u;
+                            if (light < S.n_point_lights) {   // InShadow returned (:1371-1377)
+                                if (!q_has) color = color + diffuse_specular(mat, S.point_lights[light], c.x, c.n_shading, c.w0);
+                                continue;
+                            }
+                            // the closest hit towards the light sample returned (:1405-1411)
+                            const DAreaLight& al = A.area_lights[light - S.n_point_lights];
+                            const V3 wi = mk(__uint_as_float(PSQ(PS_DX, q)), __uint_as_float(PSQ(PS_DY, q)), __uint_as_float(PSQ(PS_DZ, q)));
+                            const float dist_to_light = __uint_as_float(PSQ(PS_DIST, q));
+                            bool in_sh = false;
+                            if (q_has) {
+                                const V3 so = c.x + c.n_shading * eps;
+                                const V3 sh_x = so + wi * __uint_as_float(PSQ(PS_T, q));
+                                const float dist_to_hit = vlen(sh_x - so);
+                                if (dist_to_hit < dist_to_light - eps) in_sh = true;
+                            }
+                            if (!in_sh) {   // :1413-1431
+                                float cos_light = fabsf(dot(mk(al.nx, al.ny, al.nz), wi * -1.0f));
+                                float area = al.size * al.size;
+                                float solid_angle = (area * cos_light) / (dist_to_light * dist_to_light);
+                                V3 irradiance = mk(al.rx, al.ry, al.rz) * solid_angle;
+                                float nd = dot(c.n_shading, wi);
+                                float cos_theta = (0.0f < nd) ? nd : 0.0f;
+                                V3 diffuse = emul(ldv(mat.kd), irradiance) * cos_theta;
+                                V3 h = normalize(wi + c.w0);
+                                float nh = dot(c.n_shading, h);
+                                float cos_alpha = (0.0f < nh) ? nh : 0.0f;
+                                float spec_factor = rt_powf(cos_alpha, mat.phong);
+                                V3 specular = emul(ldv(mat.ks), irradiance) * spec_factor;
+                                color = (color + diffuse) + specular;
+                            }
                         }
-                        if (!in_sh) {   // :1413-1431
-                            float cos_light = fabsf(dot(mk(al.nx, al.ny, al.nz), wi * -1.0f));
-                            float area = al.size * al.size;
-                            float solid_angle = (area * cos_light) / (dist_to_light * dist_to_light);
-                            V3 irradiance = mk(al.rx, al.ry, al.rz) * solid_angle;
-                            float nd = dot(c.n_shading, wi);
-                            float cos_theta = (0.0f < nd) ? nd : 0.0f;
-                            V3 diffuse = emul(ldv(mat.kd), irradiance) * cos_theta;
-                            V3 h = normalize(wi + c.w0);
-                            float nh = dot(c.n_shading, h);
-                            float cos_alpha = (0.0f < nh) ? nh : 0.0f;
-                            float spec_factor = rt_powf(cos_alpha, mat.phong);
-                            V3 specular = emul(ldv(mat.ks), irradiance) * spec_factor;
-                            color = (color + diffuse) + specular;
-                        }
-                        light++;
-                        next_area = true;
+                        post_lights = true;
                     }
 
                     if (to_lights) {
                         color = color + emul(ldv(S.ambient), ldv(mat.ka));           // :1368
                         light = 0;
-                        next_point = true;
+                        post_lights = true;
                     }
-                    // ---- the light loops: post the next test, or finish the frame
-                    if (next_point) {
-                        if (light < S.n_point_lights) {
-                            const DPointLight Lp = S.point_lights[light];            // InShadow, :1008-1020
-                            V3 toLight = mk(Lp.px, Lp.py, Lp.pz) - c.x;
-                            float dist = vlen(toLight);
-                            L.o = c.x + c.n_shading * eps;
-                            L.d = vdiv(toLight, dist);
-                            L.dist = dist;
-                            L.req = OREQ_ANYHIT;
-                            n_shadow++;
-                            OFR_U(depth, OF_STAGE) = OS_POINT;
+                    // ---- the light loops (:1370-1433): post the next K tests — point lights first, then the area lights, whose
+                    // two draws each are made here, in the reference's order — or finish the frame
+                    if (post_lights) {
+                        if (light < n_lights) {
+                            const uint32_t nl = min((uint32_t)K, n_lights - light);
+                            const V3 so = c.x + c.n_shading * eps;
+                            // Slots are filled in reverse: the area lights' closest-hit rays, the long ones, get the low slots, which
+                            // the wave's trace loop starts with; the any-hit rays towards the point lights fill lanes as they fall idle.
+                            for (uint32_t qq = 0; qq < nl; qq++) {
+                                const uint32_t j = light + qq, q = nl - 1u - qq;
+                                V3 rd;
+                                float rdist;
+                                uint32_t kind;
+                                if (j < S.n_point_lights) {
+                                    const DPointLight Lp = S.point_lights[j];            // InShadow, :1008-1020
+                                    V3 toLight = mk(Lp.px, Lp.py, Lp.pz) - c.x;
+                                    rdist = vlen(toLight);
+                                    rd = vdiv(toLight, rdist);
+                                    kind = OREQ_ANYHIT;
+                                } else {
+                                    const DAreaLight& al = A.area_lights[j - S.n_point_lights];   // :1380-1403
+                                    float u = (gen.uniform() - 0.5f) * al.size;
+                                    float v = (gen.uniform() - 0.5f) * al.size;
+                                    V3 tangent, bitangent;
+                                    orthonormal_basis(mk(al.nx, al.ny, al.nz), tangent, bitangent);
+                                    V3 sample = (mk(al.px, al.py, al.pz) + tangent * u) + bitangent * v;
+                                    V3 to_light = sample - c.x;
+                                    rdist = vlen(to_light);
+                                    rd = vdiv(to_light, rdist);
+                                    kind = OREQ_CLOSEST;
+                                }
+                                PSQ(PS_OX, q) = __float_as_uint(so.x); PSQ(PS_OY, q) = __float_as_uint(so.y); PSQ(PS_OZ, q) = __float_as_uint(so.z);
+                                PSQ(PS_DX, q) = __float_as_uint(rd.x); PSQ(PS_DY, q) = __float_as_uint(rd.y); PSQ(PS_DZ, q) = __float_as_uint(rd.z);
+                                PSQ(PS_DIST, q) = __float_as_uint(rdist);
+                                PSQ(PS_REQ, q) = kind;
+                                n_shadow++;
+                            }
+                            lights_posted = true;
+                            OFR_U(depth, OF_STAGE) = OS_LIGHTS;
                             OFR_U(depth, OF_LIGHT) = light;
-                        } else {
-                            light = 0;
-                            next_area = true;
-                        }
-                    }
-                    if (next_area) {
-                        if (light < A.n_area_lights) {
-                            const DAreaLight& al = A.area_lights[light];              // :1380-1403
-                            float u = (gen.uniform() - 0.5f) * al.size;
-                            float v = (gen.uniform() - 0.5f) * al.size;
-                            V3 tangent, bitangent;
-                            orthonormal_basis(mk(al.nx, al.ny, al.nz), tangent, bitangent);
-                            V3 sample = (mk(al.px, al.py, al.pz) + tangent * u) + bitangent * v;
-                            V3 to_light = sample - c.x;
-                            float dist_to_light = vlen(to_light);
-                            V3 wi = vdiv(to_light, dist_to_light);
-                            L.o = c.x + c.n_shading * eps;
-                            L.d = wi;
-                            L.req = OREQ_CLOSEST;
-                            n_shadow++;
-                            OFR_U(depth, OF_STAGE) = OS_AREA;
-                            OFR_U(depth, OF_LIGHT) = light;
-                            OFR(depth, OF_WX) = wi.x; OFR(depth, OF_WY) = wi.y; OFR(depth, OF_WZ) = wi.z;
-                            OFR(depth, OF_DIST) = dist_to_light;
                         } else {
                             ret = color;
                             do_return = true;
@@ -510,7 +529,7 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
                         ret_pending = true;
                         continue;
                     }
-                    if (L.req != OREQ_NONE) break;
+                    if (lights_posted) break;
                 }
             }
             // ---- the slot's state goes back to memory
@@ -523,16 +542,19 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
                 PSF(PS_HIT_W0) = hit_w0; PSF(PS_HIT_TRI) = hit_tri;
                 PSF(PS_GEN_IDX) = gen.idx;
                 PSF(PS_TIME) = __float_as_uint(L.time);
-                PSF(PS_OX) = __float_as_uint(L.o.x); PSF(PS_OY) = __float_as_uint(L.o.y); PSF(PS_OZ) = __float_as_uint(L.o.z);
-                PSF(PS_DX) = __float_as_uint(L.d.x); PSF(PS_DY) = __float_as_uint(L.d.y); PSF(PS_DZ) = __float_as_uint(L.d.z);
-                PSF(PS_DIST) = __float_as_uint(L.dist);
+                if (!lights_posted) {      // (a batch of light tests is in the slots already)
+                    PSF(PS_OX) = __float_as_uint(L.o.x); PSF(PS_OY) = __float_as_uint(L.o.y); PSF(PS_OZ) = __float_as_uint(L.o.z);
+                    PSF(PS_DX) = __float_as_uint(L.d.x); PSF(PS_DY) = __float_as_uint(L.d.y); PSF(PS_DZ) = __float_as_uint(L.d.z);
+                    PSF(PS_DIST) = __float_as_uint(L.dist);
+                }
                 any_pixel = true;
             }
-            PSF(PS_REQ) = done ? (uint32_t)OREQ_NONE : (uint32_t)L.req;
-            any_request = any_request || (!done && L.req != OREQ_NONE);
+            if (!lights_posted) PSF(PS_REQ) = done ? (uint32_t)OREQ_NONE : (uint32_t)L.req;
+            any_request = !done && (lights_posted || L.req != OREQ_NONE);
 #undef OFR
 #undef OFR_U
 #undef PSF
+#undef PSQ
         }
         // a slot that became empty in this round takes a new pixel in the next one, unless the chunk has none left
         if (!__any(any_pixel) && drained) break;

@@ -77,11 +77,21 @@ def test_synthetic_multisample_dof_vs_oracle(rt):
     _vs_oracle(rt, rt.scenes.spheres_scene(200, 150, num_samples=16, dof=True))
 
 
-def test_synthetic_glossy_and_area_light_vs_oracle(rt):
-    """rough reflection / refraction and an area light — the pixel's generator is consumed in
-    recursion order (rt_ordered.h).  Image, hit ids and ray counts against the oracle."""
+@pytest.mark.parametrize("lights", ["1+1", "3+2", "0+3"])
+def test_synthetic_glossy_and_area_light_vs_oracle(rt, lights):
+    """rough reflection / refraction and area lights — the pixel's generator is consumed in
+    recursion order (rt_ordered.h).  Image, hit ids and ray counts against the oracle.  A hit posts its light tests
+    RT_ORDERED_REQS at a time: "3+2" (three point lights, two area lights) and "0+3" need several batches, with point
+    and area lights in one batch and batches that end between two area lights' draws."""
     from oracle import binding as ob
     spec = rt.scenes.glossy_area_scene(grid=48, width=320, height=200, num_samples=4)
+    if lights == "3+2":
+        spec.point_lights = spec.point_lights + [((4, 5, 3), (2500, 2600, 2400)), ((0, 7, -3), (1800, 1500, 1500))]
+        spec.area_lights = spec.area_lights + [((-2.0, 4.5, 1.0), (0.2, -1.0, 0.1), 1.0, (5000, 4800, 4500))]
+    elif lights == "0+3":
+        spec.point_lights = []
+        spec.area_lights = spec.area_lights + [((-2.0, 4.5, 1.0), (0.2, -1.0, 0.1), 1.0, (5000, 4800, 4500)),
+                                               ((2.5, 4.0, -1.5), (-0.3, -1.0, 0.2), 0.8, (4000, 4200, 4600))]
     hs = spec.build()
     cam = hs.camera(0)
     ds = rt.DeviceScene(hs, 0)
