@@ -164,7 +164,7 @@ struct OrderedArgs {
 };
 
 #ifndef RT_ORDERED_MIN_BLOCKS
-#define RT_ORDERED_MIN_BLOCKS 3  // workgroups per CU the register budget is set for
+#define RT_ORDERED_MIN_BLOCKS 2  // workgroups per CU the register budget is set for: 256 VGPRs, 63 spilled (3: 168 VGPRs, 339 spilled, 10 % slower; 4: 22 % slower; 1: 26 % slower)
 #endif
 template <bool NEAR>
 __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pixel_ordered(DScene S, OrderedArgs A, Control* ctl, uint2* spill, uint4* cand) {
