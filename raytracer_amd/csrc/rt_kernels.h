@@ -114,21 +114,44 @@ struct MtGlobal {
     uint32_t* mt;
     size_t stride;
     uint32_t idx;
+    // The FIRST block after seeding is made without the seeded state ever being written: seed word i is a chain
+    // s_i = 1812433253 * (s_{i-1} ^ (s_{i-1} >> 30)) + i, and making word k of the first block needs the seed words k,
+    // k + 1 and (k < 227) k + 397 — two running values of that chain, `lo` at k and `hi` at k + 397 — or (k >= 227)
+    // the new word k - 227, which is in memory.  seed() is then 397 multiply-adds in registers instead of 624 strided
+    // stores a lane (100 us for a wave of the depth-first pixel loop whenever one of its lanes starts a pixel).
+    uint32_t lo, hi;
+    bool first;
     __device__ __forceinline__ uint32_t& w(uint32_t k) { return mt[(size_t)k * stride]; }
+    static __device__ __forceinline__ uint32_t seed_step(uint32_t s, uint32_t i) { return 1812433253u * (s ^ (s >> 30)) + i; }
     __device__ void seed(uint32_t s) {
-        w(0) = s;
-        for (uint32_t i = 1; i < 624; i++) {
-            s = 1812433253u * (s ^ (s >> 30)) + i;
-            w(i) = s;
-        }
-        idx = 624;
+        lo = s;
+        uint32_t h = s;
+        for (uint32_t i = 1; i <= 397; i++) h = seed_step(h, i);
+        hi = h;
+        first = true;
+        idx = 0;
     }
+    __device__ __forceinline__ uint32_t packed_idx() const { return idx | (first ? 0x80000000u : 0u); }
+    __device__ __forceinline__ void unpack(uint32_t p, uint32_t l, uint32_t h) { idx = p & 0x7FFFFFFFu; first = (p >> 31) != 0u; lo = l; hi = h; }
     // std::mersenne_twister_engine regenerates all 624 words when the block is used up (_M_gen_rand) and then hands them
     // out one by one.  Here word k of the new block is made when it is handed out: it needs the old words k, k + 1 and
     // (k < 227) k + 397, none of them overwritten yet, or (k >= 227) the new word k - 227, made 227 draws ago — the same
     // values in the same order, without a 624-word loop that stalls the 63 other lanes of a wave whenever one lane's
     // block runs out (lanes of the depth-first pixel loop use up their blocks at different moments: 95 us per stall).
     __device__ __forceinline__ uint32_t next() {
+        if (first) {
+            const uint32_t k = idx;                                   // 0 .. 623
+            const uint32_t s1 = seed_step(lo, k + 1);                 // seed word k + 1
+            const uint32_t b = (k == 623) ? w(0) : s1;                // (word 0 of this block is made already)
+            const uint32_t m = (k < 227) ? hi : w(k - 227);
+            const uint32_t v = mt_mix(lo, b, m);
+            w(k) = v;
+            lo = s1;
+            if (k < 227) hi = seed_step(hi, k + 398);
+            idx = k + 1;
+            first = idx < 624;
+            return mt_temper(v);
+        }
         if (idx >= 624) idx = 0;
         const uint32_t k = idx;
         const uint32_t k1 = (k + 1 == 624) ? 0 : k + 1;

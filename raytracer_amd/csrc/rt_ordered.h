@@ -80,7 +80,7 @@ enum {
     PS_ACC_R, PS_ACC_G, PS_ACC_B,
     PS_RET_R, PS_RET_G, PS_RET_B,
     PS_HIT_W0, PS_HIT_TRI,
-    PS_GEN_IDX, PS_TIME,
+    PS_GEN_IDX, PS_GEN_LO, PS_GEN_HI, PS_TIME,
     // per request slot
     PS_REQ, PS_OX, PS_OY, PS_OZ, PS_DX, PS_DY, PS_DZ, PS_DIST,          // the request: OREQ_*, ray, InShadow's distance
     PS_HAS, PS_T, PS_KIND, PS_TRI, PS_BETA, PS_GAMMA,                   // the answer
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
     for (uint32_t k = 0; k < K; k++) io.f(PS_REQ, k * 64u + ww.lane) = OREQ_NONE;
 
 #ifdef RT_ORDERED_TIMES
-    unsigned long long tk_shade = 0, tk_trace = 0, tk_rounds = 0, tk_t0 = (unsigned long long)wall_clock64(), tk_tw = 0, tk_init = 0, n_tw = 0;
+    unsigned long long tk_shade = 0, tk_trace = 0, tk_rounds = 0, tk_t0 = (unsigned long long)wall_clock64(), tk_init = 0, tk_iters = 0, tk_loop = 0, tk_active = 0;
 #endif
     for (;;) {
 #ifdef RT_ORDERED_TIMES
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
             LaneTrace L;
             L.req = OREQ_NONE; L.has = false; L.t = 0.f; L.kind_index = 0xFFFFFFFFu; L.tri = 0; L.beta = L.gamma = 0.f;
             L.o = L.d = mk(0, 0, 0); L.time = 0.f; L.dist = 0.f;
-            gen.idx = 624;
+            gen.idx = 624; gen.first = false; gen.lo = gen.hi = 0;
 
             // ---- an empty slot takes the next pixel of the chunk (one atomic per wave)
             if (!drained) {
@@ -281,15 +281,22 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
                 acc_color = mk(__uint_as_float(PSF(PS_ACC_R)), __uint_as_float(PSF(PS_ACC_G)), __uint_as_float(PSF(PS_ACC_B)));
                 ret = mk(__uint_as_float(PSF(PS_RET_R)), __uint_as_float(PSF(PS_RET_G)), __uint_as_float(PSF(PS_RET_B)));
                 hit_w0 = PSF(PS_HIT_W0); hit_tri = PSF(PS_HIT_TRI);
-                gen.idx = PSF(PS_GEN_IDX);
+                gen.unpack(PSF(PS_GEN_IDX), PSF(PS_GEN_LO), PSF(PS_GEN_HI));
                 L.time = __uint_as_float(PSF(PS_TIME));
                 L.has = PSF(PS_HAS) != 0u; L.t = __uint_as_float(PSF(PS_T)); L.kind_index = PSF(PS_KIND); L.tri = PSF(PS_TRI);
                 L.beta = __uint_as_float(PSF(PS_BETA)); L.gamma = __uint_as_float(PSF(PS_GAMMA));
             }
 
             // ---- run ApplyShading forward until it needs a ray traced (or the pixel is finished)
+#ifdef RT_ORDERED_TIMES
+            const unsigned long long tl_a = (unsigned long long)wall_clock64();
+            unsigned tk_my_iters = 0;
+#endif
             if (!done) {
                 for (;;) {
+#ifdef RT_ORDERED_TIMES
+                    tk_my_iters++;
+#endif
                     if (start_sample) {            // raytracer.cpp:56-74
                         start_sample = false;
                         const int sx = s % sps, sy = s / sps;
@@ -532,6 +539,15 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
                     if (lights_posted) break;
                 }
             }
+#ifdef RT_ORDERED_TIMES
+            {
+                unsigned mx = tk_my_iters;
+                for (int off = 32; off; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+                tk_iters += mx;
+                tk_active += tk_my_iters;
+                tk_loop += (unsigned long long)wall_clock64() - tl_a;
+            }
+#endif
             // ---- the slot's state goes back to memory
             PSF(PS_IDX) = idx;
             if (!done) {
@@ -540,7 +556,7 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
                 PSF(PS_ACC_R) = __float_as_uint(acc_color.x); PSF(PS_ACC_G) = __float_as_uint(acc_color.y); PSF(PS_ACC_B) = __float_as_uint(acc_color.z);
                 PSF(PS_RET_R) = __float_as_uint(ret.x); PSF(PS_RET_G) = __float_as_uint(ret.y); PSF(PS_RET_B) = __float_as_uint(ret.z);
                 PSF(PS_HIT_W0) = hit_w0; PSF(PS_HIT_TRI) = hit_tri;
-                PSF(PS_GEN_IDX) = gen.idx;
+                PSF(PS_GEN_IDX) = gen.packed_idx(); PSF(PS_GEN_LO) = gen.lo; PSF(PS_GEN_HI) = gen.hi;
                 PSF(PS_TIME) = __float_as_uint(L.time);
                 if (!lights_posted) {      // (a batch of light tests is in the slots already)
                     PSF(PS_OX) = __float_as_uint(L.o.x); PSF(PS_OY) = __float_as_uint(L.o.y); PSF(PS_OZ) = __float_as_uint(L.o.z);
@@ -575,8 +591,9 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
     }
 #ifdef RT_ORDERED_TIMES
     if (ww.lane == 0 && (((blockIdx.x % 97) == 0 && ww.wave == 0) || ((unsigned long long)wall_clock64() - tk_t0) > 26000000ull))
-        printf("[ordered] block %d: life %.0f us, %llu rounds: shade %.0f us (%.1f per round), trace %.0f us (%.1f per round) | lane 0: pixel init %.0f us\n", (int)blockIdx.x,
-               ((unsigned long long)wall_clock64() - tk_t0) * 0.01, tk_rounds, tk_shade * 0.01, tk_shade * 0.01 / tk_rounds, tk_trace * 0.01, tk_trace * 0.01 / tk_rounds, tk_init * 0.01);
+        printf("[ordered] block %d: life %.0f us, %llu rounds: shade %.0f us (%.1f per round), trace %.0f us (%.1f per round) | lane 0: pixel init %.0f us | loop %.1f us per round, %.2f wave passes per round, lane 0 %.2f\n", (int)blockIdx.x,
+               ((unsigned long long)wall_clock64() - tk_t0) * 0.01, tk_rounds, tk_shade * 0.01, tk_shade * 0.01 / tk_rounds, tk_trace * 0.01, tk_trace * 0.01 / tk_rounds, tk_init * 0.01,
+               tk_loop * 0.01 / tk_rounds, (double)tk_iters / tk_rounds, (double)tk_active / tk_rounds);
 #endif
     if (st.overflow) atomicOr(&ctl->overflow, (st.overflow & 48u) | ((st.overflow & ~48u) ? 4u : 0u));
 #ifdef RT_TRACE_STATS
