@@ -130,7 +130,7 @@ struct rt_scene {
     // work memory
     Pool pool{};
     DevBuf b_ray0, b_ray1, b_hit0, b_hit1, b_nrm, b_link, b_color, b_shadow_rec, b_shadow_lit;
-    DevBuf b_ctl, b_spill, b_cand, b_mt, b_frames, b_pstate, b_fb, b_hits;
+    DevBuf b_ctl, b_spill, b_cand, b_mt, b_frames, b_pstate, b_tile_order, b_fb, b_hits;
     DevBuf b_wq, b_sq;          // rt_mega.h: work rings of the trace workgroups, rings to their shading waves
     Control* h_ctl = nullptr;   // pinned
     void* h_stage = nullptr;    // pinned staging for rt_render_tile's host outputs
@@ -1017,6 +1017,33 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         A.row_stride = stride;
         A.hit_ids = d_hits;
         A.tri_shade = sc->ds.tri_shade;
+        A.tile_order = nullptr;
+        // Costliest tiles first (k_tile_cost): one centre ray per pixel through the generation pipeline's first two
+        // kernels, the tiles sorted on the host.  Worth it when the launch hands out many more tiles than it has waves.
+        if (grid > 0 && !getenv("RT_ORDERED_IMAGE_ORDER") && ((N > 1 && total_tiles >= 4u * (uint32_t)grid * (RT_ORDERED_BLOCK / 64)) || getenv("RT_ORDERED_COST_ORDER"))) {
+            if ((rc = ensure_pool(sc, n_idx))) return rc;
+            if ((rc = sc->b_tile_order.ensure((size_t)total_tiles * 8))) return rc;
+            uint32_t* d_cost = (uint32_t*)sc->b_tile_order.p + total_tiles;
+            DCamera dc1 = dc;
+            dc1.num_samples = 1;
+            dc1.sps = 1;
+            if ((rc = tm.begin(TC_RAYGEN))) return rc;
+            k_init_chunk<<<1, 64, 0, st>>>(ctl, n_idx);
+            k_raygen_single<<<(n_idx + 255) / 256, 256, 0, st>>>(dc1, A.g, sc->pool);
+            if (near) k_trace_closest<true><<<blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, sc->pool, ctl, 0, spill, cand);
+            else k_trace_closest<false><<<blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, sc->pool, ctl, 0, spill, cand);
+            k_tile_cost<<<(n_idx + 255) / 256, 256, 0, st>>>(sc->ds, sc->pool, n_idx, d_cost);
+            std::vector<uint32_t> cost(total_tiles), order(total_tiles);
+            HIPCHK(hipMemcpyAsync(cost.data(), d_cost, (size_t)total_tiles * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (uint32_t t = 0; t < total_tiles; t++) order[t] = t;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+            HIPCHK(hipMemcpyAsync(sc->b_tile_order.p, order.data(), (size_t)total_tiles * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));                  // (`order` leaves scope)
+            HIPCHK(hipMemsetAsync(ctl, 0, sizeof(Control), st));   // cursors and ray counters start again
+            if ((rc = tm.end())) return rc;
+            A.tile_order = (const uint32_t*)sc->b_tile_order.p;
+        }
         if (grid > 0) {
             if ((rc = tm.begin(TC_CLOSEST))) return rc;
             if (near) k_pixel_ordered<true><<<grid, RT_ORDERED_BLOCK, 0, st>>>(sc->ds, A, ctl, spill, cand);
@@ -1470,7 +1497,7 @@ void rt_free_scene(rt_scene* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (DevBuf* b : {&s->b_big, &s->b_nodes, &s->b_tris, &s->b_tri_shade, &s->b_vnormals, &s->b_objects, &s->b_top_prims, &s->b_planes,
                       &s->b_materials, &s->b_lights, &s->b_ray0, &s->b_ray1, &s->b_hit0, &s->b_hit1, &s->b_nrm, &s->b_link,
-                      &s->b_color, &s->b_shadow_rec, &s->b_shadow_lit, &s->b_ctl, &s->b_spill, &s->b_cand, &s->b_mt, &s->b_frames, &s->b_pstate, &s->b_area_lights, &s->b_fb, &s->b_hits, &s->b_tri_rank, &s->b_wq, &s->b_sq})
+                      &s->b_color, &s->b_shadow_rec, &s->b_shadow_lit, &s->b_ctl, &s->b_spill, &s->b_cand, &s->b_mt, &s->b_frames, &s->b_pstate, &s->b_tile_order, &s->b_area_lights, &s->b_fb, &s->b_hits, &s->b_tri_rank, &s->b_wq, &s->b_sq})
         b->release();
     for (auto& e : s->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }

@@ -161,7 +161,32 @@ struct OrderedArgs {
     size_t row_stride;
     uint32_t* hit_ids;
     const DTriShade* tri_shade;
+    const uint32_t* tile_order;  // NULL, or the order in which the cursor hands out the chunk's 8x8 tiles (costliest first, k_tile_cost)
 };
+
+// What a tile will cost, from the closest hit of one ray per pixel (the records of a k_raygen_single / k_trace_closest
+// pass over the chunk): pixels that open a refraction tree weigh most.  The launch is as long as its costliest pixels'
+// chains of sequential rays, so those pixels start first; the order changes no pixel's rays.
+__global__ void __launch_bounds__(256) k_tile_cost(DScene S, Pool P, uint32_t n_idx, uint32_t* cost) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t w = 0;
+    if (idx < n_idx) {
+        const uint4 h0 = P.hit0[idx];
+        w = 1;
+        if (h0.y != 0xFFFFFFFFu) {
+            const uint32_t kind = h0.y >> 28, index = h0.y & 0x0FFFFFFFu;
+            int mid = 1;
+            if (kind == RT_KIND_MESH) mid = S.objects[S.mesh_obj_base + index].material_id;
+            else if (kind == RT_KIND_TRIANGLE) mid = S.objects[S.tri_obj_base + index].material_id;
+            else if (kind == RT_KIND_SPHERE) mid = S.objects[S.sphere_obj_base + index].material_id;
+            else mid = S.planes[index].material_id;
+            const int type = S.materials[mid - 1].type;
+            w = type == RT_MAT_DIELECTRIC ? 24u : ((type == RT_MAT_MIRROR || type == RT_MAT_CONDUCTOR) ? 6u : 3u);
+        }
+    }
+    for (int off = 32; off; off >>= 1) w += (uint32_t)__shfl_xor((int)w, off, 64);
+    if ((threadIdx.x & 63u) == 0 && idx < n_idx) cost[idx >> 6] = w;
+}
 
 #ifndef RT_ORDERED_MIN_BLOCKS
 #define RT_ORDERED_MIN_BLOCKS 2  // workgroups per CU the register budget is set for: 256 VGPRs, 63 spilled (3: 168 VGPRs, 339 spilled, 10 % slower; 4: 22 % slower; 1: 26 % slower)
@@ -236,8 +261,9 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
                     if (base + (uint32_t)__popcll(empty) >= A.g.n_idx) drained = true;
                     if (idx == RT_SLOT_EMPTY) {
                         const uint32_t cand_idx = base + (uint32_t)__popcll(empty & ((1ull << ww.lane) - 1ull));
-                        if (cand_idx < A.g.n_idx && idx_to_pixel(A.g, cand_idx, px, py)) {
-                            idx = cand_idx;
+                        const uint32_t mapped = (A.tile_order && cand_idx < A.g.n_idx) ? A.tile_order[cand_idx >> 6] * 64u + (cand_idx & 63u) : cand_idx;
+                        if (cand_idx < A.g.n_idx && idx_to_pixel(A.g, mapped, px, py)) {
+                            idx = mapped;
 #ifdef RT_ORDERED_TIMES
                             const unsigned long long ti_a = (unsigned long long)wall_clock64();
 #endif

@@ -77,13 +77,16 @@ def test_synthetic_multisample_dof_vs_oracle(rt):
     _vs_oracle(rt, rt.scenes.spheres_scene(200, 150, num_samples=16, dof=True))
 
 
-@pytest.mark.parametrize("lights", ["1+1", "3+2", "0+3"])
-def test_synthetic_glossy_and_area_light_vs_oracle(rt, lights):
+@pytest.mark.parametrize("lights", ["1+1", "3+2", "0+3", "1+1 costliest tiles first"])
+def test_synthetic_glossy_and_area_light_vs_oracle(rt, lights, monkeypatch):
     """rough reflection / refraction and area lights — the pixel's generator is consumed in
     recursion order (rt_ordered.h).  Image, hit ids and ray counts against the oracle.  A hit posts its light tests
     RT_ORDERED_REQS at a time: "3+2" (three point lights, two area lights) and "0+3" need several batches, with point
-    and area lights in one batch and batches that end between two area lights' draws."""
+    and area lights in one batch and batches that end between two area lights' draws.  The last case forces the
+    tile order large renders get (a centre-ray pass, costliest 8x8 tiles handed out first): same bytes, same counts."""
     from oracle import binding as ob
+    if lights.endswith("first"):
+        monkeypatch.setenv("RT_ORDERED_COST_ORDER", "1")
     spec = rt.scenes.glossy_area_scene(grid=48, width=320, height=200, num_samples=4)
     if lights == "3+2":
         spec.point_lights = spec.point_lights + [((4, 5, 3), (2500, 2600, 2400)), ((0, 7, -3), (1800, 1500, 1500))]
