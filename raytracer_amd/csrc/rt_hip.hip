@@ -969,8 +969,8 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
     }
     // what the shading waves' slabs may hold without using it: one slab per workgroup, and up to a batch's worth (64
     // records with two children each; 64 x lights slots) at the end of every slab, a sixteenth of it
-    const uint64_t mega_slack_rec = (uint64_t)blocks_closest * RT_MEGA_REC_SLAB;
-    const uint64_t mega_slack_sh = (uint64_t)blocks_closest * std::max<uint64_t>(RT_MEGA_SH_SLAB, 1024ull * sc->n_point_lights);
+    const uint64_t mega_slack_rec = (uint64_t)blocks_closest * RT_MEGA_SHADERS * RT_MEGA_REC_SLAB;
+    const uint64_t mega_slack_sh = (uint64_t)blocks_closest * RT_MEGA_SHADERS * std::max<uint64_t>(RT_MEGA_SH_SLAB, 1024ull * sc->n_point_lights);
     if (!sc->needs_sequential_rng && !ws) {
         // records: one per primary sample, and with child rays about twice that (a chunk that overflows is redone
         // with half the pixels): room for four per sample of the largest chunk

@@ -38,7 +38,10 @@
 #include "rt_kernels.h"
 
 #define RT_MEGA_WAVES (RT_TRACE_BLOCK / 64)
-#define RT_MEGA_TRACERS (RT_MEGA_WAVES - 1)   // tracing waves per workgroup; the last wave shades
+#ifndef RT_MEGA_SHADERS
+#define RT_MEGA_SHADERS 1           // shading waves per workgroup (the last ones); shading wave k serves the tracing waves t with t % SHADERS == k
+#endif
+#define RT_MEGA_TRACERS (RT_MEGA_WAVES - RT_MEGA_SHADERS)   // tracing waves per workgroup
 #ifndef RT_MEGA_SQ_CAP
 #define RT_MEGA_SQ_CAP 2048u        // entries of a tracing wave's ring to the shading wave (power of two)
 #endif
@@ -336,7 +339,7 @@ struct MegaIO {
 };
 
 // The shading wave (wave 15).  Returns when the workgroup is finished.
-__device__ void mega_shading_wave(const DScene& S, MegaIO& io, const uint32_t* blk, uint32_t* sq_all, uint32_t parts, uint32_t lane) {
+__device__ void mega_shading_wave(const DScene& S, MegaIO& io, const uint32_t* blk, uint32_t* sq_all, uint32_t parts, uint32_t lane, uint32_t shader) {
     MegaLds& M = *io.M;
     uint32_t waited = 0, spins = 0;
     const uint64_t lanes_below = (1ull << lane) - 1ull;
@@ -344,7 +347,7 @@ __device__ void mega_shading_wave(const DScene& S, MegaIO& io, const uint32_t* b
         if (lds_read(&M.abort) != 0u) break;
         // ---- what the tracing waves have handed over: up to 64 records, ring by ring
         uint32_t avail = 0, head = 0;
-        if (lane < RT_MEGA_TRACERS) { head = lds_read(&M.sq_head[lane]); avail = lds_read(&M.sq_tail[lane]) - head; }
+        if (lane < RT_MEGA_TRACERS && lane % RT_MEGA_SHADERS == shader) { head = lds_read(&M.sq_head[lane]); avail = lds_read(&M.sq_tail[lane]) - head; }
         uint32_t incl = avail;
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) {
@@ -404,8 +407,8 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_mega(DSc
     uint32_t* sq_all = A.sq + (size_t)blockIdx.x * RT_MEGA_TRACERS * RT_MEGA_SQ_CAP;
     MegaIO io{ClosestIO{S, P}, ShadowIO{S, P}, ctl, &s_mega, cq, aq, sq_all + (size_t)(ww.wave % RT_MEGA_TRACERS) * RT_MEGA_SQ_CAP, ww.wave,
               ww.wave >= RT_MEGA_TRACERS - A.any_waves, A.strict != 0, A.n_primary, 0u, 0u, 0u, 0u, 0ull, 0xFFFFFFFFu, 0u, false};
-    if (ww.wave == RT_MEGA_TRACERS) {
-        mega_shading_wave(S, io, s_lds.blk, sq_all, parts, ww.lane);
+    if (ww.wave >= RT_MEGA_TRACERS) {
+        mega_shading_wave(S, io, s_lds.blk, sq_all, parts, ww.lane, ww.wave - RT_MEGA_TRACERS);
         return;
     }
 #ifdef RT_TRACE_STATS

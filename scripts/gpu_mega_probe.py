@@ -43,6 +43,12 @@ if "mid" in which:
         run(f"inst10 {w}x{h}", scenes.instanced_scene(709, w, h), oracle=False, reps=5)
         run(f"spheres {w}x{h}", scenes.spheres_scene(w, h), oracle=False, reps=8)
     run("mesh g96 4spp 640x360", scenes.mesh_scene(grid=96, width=640, height=360, num_samples=4), oracle=False, reps=8)
+if "hd" in which:
+    run("mesh g96 640x360", scenes.mesh_scene(grid=96, width=640, height=360))
+    run("mesh1m 1280x720", scenes.mesh_scene(709, 1280, 720), oracle=False, reps=8)
+    run("mesh1m 1920x1080", scenes.mesh_scene(709, 1920, 1080), oracle=False, reps=8)
+    run("inst10 1920x1080", scenes.instanced_scene(709, 1920, 1080), oracle=False, reps=5)
+    run("mesh1m 4K", scenes.mesh_scene(709, 3840, 2160), oracle=False, reps=4)
 if "big" in which:
     run("mesh1m 1080p", scenes.mesh_scene(709, 1920, 1080), oracle=False, reps=10)
     run("inst10 1080p", scenes.instanced_scene(709, 1920, 1080), oracle=False, reps=5)
