@@ -1190,7 +1190,8 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
                 ln = std::min<uint32_t>(ln, RT_TL_LOG);
                 std::vector<uint32_t> order(ln);
                 for (uint32_t i = 0; i < ln; i++) order[i] = i;
-                std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lg[a][6] > lg[b][6]; });
+                const int key = getenv("RT_TL_BY_LIFE") ? 2 : 6;   // the longest-lived instead of the last to finish
+                std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lg[a][key] > lg[b][key]; });
                 fprintf(stderr, "[rt tl] %u rays finished after the cursor was drained; the last 40 to finish:\n", ln);
                 for (uint32_t i = 0; i < ln && i < 40; i++) {
                     const uint32_t* o = lg[order[i]];
