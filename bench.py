@@ -14,7 +14,7 @@ N > 1   BASELINE.json configs[4] / SURVEY.md §8d M5 — the FIXED 7680x4320 fra
         rank 0 over RCCL inside the timed region.  `weak` holds the weak-scaling figure of earlier rounds
         (configs[1] with N x the pixels).
 
-  python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus 1 --steps 100 --warmup 5      (the defaults)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  Inputs (scene, ray pools) are resident in HBM before the timed region; the frame
@@ -214,8 +214,8 @@ def roofline_all_traces(acc, rays_rank, wb, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, default=709, help="mesh grid (709 -> 1 002 528 triangles)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-rebuilt", action="store_true", help="skip the rebuilt-BVH leg (so that a profile of k_trace_closest<true> is the near-first leg alone)")
