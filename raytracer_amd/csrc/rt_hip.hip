@@ -1020,8 +1020,14 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         A.tile_order = nullptr;
         // Costliest tiles first (k_tile_cost): one centre ray per pixel through the generation pipeline's first two
         // kernels, the tiles sorted on the host.  Worth it when the launch hands out many more tiles than it has waves.
-        if (grid > 0 && !getenv("RT_ORDERED_IMAGE_ORDER") && ((N > 1 && total_tiles >= 4u * (uint32_t)grid * (RT_ORDERED_BLOCK / 64)) || getenv("RT_ORDERED_COST_ORDER"))) {
+        bool cost_order = grid > 0 && !getenv("RT_ORDERED_IMAGE_ORDER") &&
+                          ((N > 1 && total_tiles >= 4u * (uint32_t)grid * (RT_ORDERED_BLOCK / 64)) || getenv("RT_ORDERED_COST_ORDER"));
+        if (cost_order) {
             if ((rc = ensure_pool(sc, n_idx))) return rc;
+            // (a record pool capped below one record per pixel — RT_OPT_POOL_RECORDS — keeps image order)
+            cost_order = sc->pool.cap_records >= n_idx;
+        }
+        if (cost_order) {
             if ((rc = sc->b_tile_order.ensure((size_t)total_tiles * 8))) return rc;
             uint32_t* d_cost = (uint32_t*)sc->b_tile_order.p + total_tiles;
             DCamera dc1 = dc;
