@@ -268,25 +268,7 @@ __global__ void __launch_bounds__(RT_ORDERED_BLOCK, RT_ORDERED_MIN_BLOCKS) k_pix
                             const unsigned long long ti_a = (unsigned long long)wall_clock64();
 #endif
                             gen.seed((uint32_t)(py * A.cam.image_w + px));
-                            for (int q = 0; q < N; q++) perm[(size_t)q * n_pix] = (uint32_t)q;
-                            int i = 1;   // std::shuffle, bits/stl_algo.h (pair path), as k_raygen_multi
-                            if ((N % 2) == 0) {
-                                uint32_t dpos = gen.lemire(2);
-                                uint32_t a = perm[(size_t)i * n_pix], b = perm[(size_t)dpos * n_pix];
-                                perm[(size_t)i * n_pix] = b; perm[(size_t)dpos * n_pix] = a;
-                                i++;
-                            }
-                            while (i < N) {
-                                uint32_t swap_range = (uint32_t)i + 1, b1 = swap_range + 1;
-                                uint32_t x = gen.lemire(swap_range * b1);
-                                uint32_t p0 = x / b1, p1 = x % b1;
-                                uint32_t a = perm[(size_t)i * n_pix], b = perm[(size_t)p0 * n_pix];
-                                perm[(size_t)i * n_pix] = b; perm[(size_t)p0 * n_pix] = a;
-                                i++;
-                                a = perm[(size_t)i * n_pix]; b = perm[(size_t)p1 * n_pix];
-                                perm[(size_t)i * n_pix] = b; perm[(size_t)p1 * n_pix] = a;
-                                i++;
-                            }
+                            mt_shuffle_identity(gen, perm, n_pix, N);   // std::shuffle, as k_raygen_multi
                             start_sample = true;
 #ifdef RT_ORDERED_TIMES
                             tk_init += (unsigned long long)wall_clock64() - ti_a;
