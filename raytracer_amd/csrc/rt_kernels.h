@@ -67,28 +67,7 @@ __device__ __forceinline__ bool idx_to_pixel(const ChunkGeom& g, uint32_t idx, i
 }
 
 #include "rt_mt.h"   // the reference's per-pixel generator, restated (host-testable)
-
-// ComputeRay, raytracer.cpp:343-378
-__device__ __forceinline__ void compute_ray(const DCamera& cam, int j, int i, float jx, float jy, float au, float av,
-                                            V3& o, V3& d) {
-    float su = (j + jx) * cam.pixel_w;
-    float sv = (i + jy) * cam.pixel_h;
-    V3 q = ldv(cam.q), u = ldv(cam.u), v = ldv(cam.v), pos = ldv(cam.pos);
-    V3 sample_point = (q + u * su) - v * sv;
-    if (!cam.dof) {
-        o = pos;
-        d = normalize(sample_point - pos);
-    } else {
-        V3 dir = normalize(pos - sample_point);
-        float t_focal = cam.focus / dot(dir, ldv(cam.w) * -1.0f);
-        V3 focal_point = pos + dir * t_focal;
-        float lens_u = (au - 0.5f) * cam.aperture;
-        float lens_v = (av - 0.5f) * cam.aperture;
-        V3 lens_sample = (pos + u * lens_u) + v * lens_v;
-        o = lens_sample;
-        d = normalize(focal_point - lens_sample);
-    }
-}
+#include "rt_shade.h" // ray generation and shading arithmetic (host-testable)
 
 __device__ __forceinline__ void write_ray(const Pool& P, uint32_t r, V3 o, V3 d, float time, bool live) {
     P.ray0[r] = make_float4(o.x, o.y, o.z, time);
@@ -383,78 +362,6 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_mixed(DS
 }
 
 // ------------------------------------------------------------------- shading
-// Everything ApplyShading derives from (ray, hit point, normal, material) before
-// it needs child colours or shadow results (raytracer.cpp:1250-1345).
-struct ShadeCtx {
-    V3 x, n_shading, w0;
-    uint32_t type;
-    // mirror / conductor
-    V3 wr;                 // reflection direction
-    V3 refl_origin;
-    float Fr;              // conductor / dielectric Fresnel
-    // dielectric
-    bool entering, tir;
-    V3 wt, refr_origin;
-};
-
-// Fresnel_Dielectric, raytracer.cpp:1459-1470
-__device__ __forceinline__ float fresnel_dielectric(float cosTheta, float cosPhi, float n1, float n2) {
-    float r_par = (n2 * cosTheta - n1 * cosPhi) / (n2 * cosTheta + n1 * cosPhi);
-    float r_perp = (n1 * cosTheta - n2 * cosPhi) / (n1 * cosTheta + n2 * cosPhi);
-    return (r_par * r_par + r_perp * r_perp) * 0.5f;
-}
-// Fresnel_Conductor, raytracer.cpp:1472-1488
-__device__ __forceinline__ float fresnel_conductor(float cosTheta, float n, float k) {
-    float cos_sq = cosTheta * cosTheta;
-    float n_sq = n * n;
-    float k_sq = k * k;
-    float two_n_cos = 2.0f * n * cosTheta;
-    float rs_num = (n_sq + k_sq) - two_n_cos + cos_sq;
-    float rs_den = (n_sq + k_sq) + two_n_cos + cos_sq;
-    float R_S = rs_num / rs_den;
-    float rp_num = (n_sq + k_sq) * cos_sq - two_n_cos + 1;
-    float rp_den = (n_sq + k_sq) * cos_sq + two_n_cos + 1;
-    float R_P = rp_num / rp_den;
-    return (R_S + R_P) * 0.5f;
-}
-
-__device__ __forceinline__ void shade_ctx(const DScene& S, const DMaterial& mat, V3 o, V3 d, float tHit, V3 n_original,
-                                          ShadeCtx& c) {
-    c.x = o + d * tHit;
-    c.n_shading = (dot(n_original, d) < 0.0f) ? n_original : n_original * -1.0f;
-    c.w0 = normalize(o - c.x);
-    c.type = mat.type;
-    c.entering = true;
-    c.tir = false;
-    c.Fr = 0.f;
-    const float eps = S.shadow_eps;
-    if (mat.type == RT_MAT_MIRROR || mat.type == RT_MAT_CONDUCTOR) {
-        c.wr = normalize((c.n_shading * 2.0f) * dot(c.n_shading, c.w0) - c.w0);   // :1274 / :1286
-        c.refl_origin = c.x + c.n_shading * eps;
-        if (mat.type == RT_MAT_CONDUCTOR) c.Fr = fresnel_conductor(dot(c.w0, c.n_shading), mat.ior, mat.absorb_index);
-    } else if (mat.type == RT_MAT_DIELECTRIC) {                                    // :1301-1362
-        c.entering = dot(n_original, d) < 0.0f;
-        V3 normal = c.entering ? n_original : n_original * -1.0f;
-        float etaI = c.entering ? 1.0f : mat.ior;
-        float etaT = c.entering ? mat.ior : 1.0f;
-        float eta = etaI / etaT;
-        float cosI = dot(c.w0, normal);
-        float one_minus = 1.0f - cosI * cosI;
-        float sin2I = (0.0f < one_minus) ? one_minus : 0.0f;
-        float sin2T = eta * eta * sin2I;
-        c.wr = normalize((normal * 2.0f) * cosI - c.w0);
-        c.refl_origin = c.x + normal * eps;
-        if (sin2T >= 1.0f) {
-            c.tir = true;
-        } else {
-            float cosT = sqrtf(1.0f - sin2T);
-            c.Fr = fresnel_dielectric(cosI, cosT, etaI, etaT);
-            c.wt = normalize((c.w0 * -1.0f) * eta + normal * (eta * cosI - cosT));
-            c.refr_origin = c.x - normal * eps;
-        }
-    }
-}
-
 // Normal reconstruction of FindClosestHit, raytracer.cpp:447-517.
 __device__ __forceinline__ V3 hit_normal(const DScene& S, uint32_t kind_index, uint32_t tri, float beta, float gamma,
                                          V3 hit_x, int& material_id) {
@@ -627,22 +534,6 @@ __global__ void k_advance(Control* ctl, Pool P, int gen) {
         for (int g = gen + 1; g < RT_MAX_GEN + 2; g++) ctl->sstart[g] = ns;
         for (int p = 0; p < RT_PARTS; p++) { ctl->cursor_closest[p * RT_CURSOR_STRIDE] = 0; ctl->cursor_shadow[p * RT_CURSOR_STRIDE] = 0; }
     }
-}
-
-// ComputeDiffuseAndSpecular, raytracer.cpp:1490-1520
-__device__ __forceinline__ V3 diffuse_specular(const DMaterial& mat, const DPointLight& L, V3 point, V3 normal, V3 w0) {
-    V3 Lv = mk(L.px, L.py, L.pz) - point;
-    V3 wi = normalize(Lv);
-    float cos_theta = dot(wi, normal);
-    if (cos_theta < 0.0f) return mk(0.0f, 0.0f, 0.f);
-    float d_sq = dot(Lv, Lv);
-    V3 irradiance = vdiv(mk(L.ix, L.iy, L.iz), d_sq);
-    V3 diffuse = emul(ldv(mat.kd) * cos_theta, irradiance);
-    V3 h = normalize(wi + w0);
-    float cos_alpha = dot(normal, h);
-    if (cos_alpha < 0.0f) return diffuse;
-    V3 spec = emul(ldv(mat.ks) * rt_powf(cos_alpha, mat.phong), irradiance);
-    return diffuse + spec;
 }
 
 // ApplyShading's colour expression (raytracer.cpp:1251-1377) for one record of depth `gen`, children already combined.

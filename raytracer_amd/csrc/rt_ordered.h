@@ -36,26 +36,6 @@ enum {
 enum { OS_TRACE = 0, OS_REFLECT_WAIT, OS_REFRACT_WAIT, OS_LIGHTS };
 enum { OREQ_NONE = 0, OREQ_CLOSEST = 1, OREQ_ANYHIT = 2 };
 
-// CreateOrthonormalBasis, raytracer.cpp:1522-1537
-__device__ __forceinline__ void orthonormal_basis(V3 n, V3& tangent, V3& bitangent) {
-    V3 helper;
-    if (fabsf(n.x) < fabsf(n.y) && fabsf(n.x) < fabsf(n.z)) helper = mk(1.0f, 0.0f, 0.0f);
-    else if (fabsf(n.y) < fabsf(n.z)) helper = mk(0.0f, 1.0f, 0.0f);
-    else helper = mk(0.0f, 0.0f, 1.0f);
-    tangent = normalize(cross(n, helper));
-    bitangent = cross(n, tangent);
-}
-// PerturbReflection, raytracer.cpp:1438-1457
-__device__ __forceinline__ V3 perturb_reflection(V3 r, float roughness, MtGlobal& gen) {
-    if (roughness <= 0.0f) return r;
-    V3 u, v;
-    orthonormal_basis(r, u, v);
-    const float xi1 = gen.uniform();
-    const float xi2 = gen.uniform();
-    V3 rr = (r + u * (roughness * (xi1 - 0.5f))) + v * (roughness * (xi2 - 0.5f));
-    return normalize(rr);
-}
-
 // ---- pixel state and request slots.  Everything a pixel needs between two of its rays lives in global memory, one
 // 4-byte field per slot, stored [field][slot] so that the 64 lanes of a wave read and write neighbouring words: the
 // pixel's place in the loop below (PS_*), its frame stack (OF_*), its generator.  The REQUESTS a pixel has posted and
