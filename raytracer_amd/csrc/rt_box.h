@@ -1,5 +1,6 @@
 // rt_box.h — the ray/box and ray/primitive arithmetic of the traversal (IntersectAABB, IntersectsTriangle_Bary,
-// IntersectSphere, IntersectsPlane: raytracer.cpp:815-999), kept free of wave-level constructs so that
+// IntersectSphere, IntersectsPlane: raytracer.cpp:815-999; the per-object ray set-up and the way back to a world
+// distance: raytracer.cpp:559-606), kept free of wave-level constructs so that
 // tests/box_logic.cpp can compile the very same text for the host and compare it with the oracle's restatement
 // of the reference over adversarial operands (zero and denormal direction components, origins on box planes,
 // degenerate boxes and triangles, infinities).  Device builds include it through rt_traverse.h, after
@@ -188,3 +189,29 @@ RT_BOX_FN bool plane_test(V3 o, V3 d, const DPlane& p, float minT, float& t_out)
     return true;
 }
 
+// Per-object ray set-up, raytracer.cpp:559-587 (and :1070-1095 for shadows).
+RT_BOX_FN void object_space_ray(const DObject& ob, V3 ro, V3 rd, float time, float minT, V3& to,
+                                                 V3& td, float& testMinT) {
+    to = ro;
+    td = rd;
+    testMinT = minT;
+    if (ob.flags & RT_OBJ_HAS_TRANSFORM) {
+        V3 o2 = ro;
+        if (ob.flags & RT_OBJ_HAS_MOTION_BLUR) o2 = o2 - mk(ob.mbx, ob.mby, ob.mbz) * time;
+        to = xf_point(ob.Minv, o2);
+        V3 objDir = xf_vector(ob.Minv, rd);
+        td = normalize(objDir);
+        float scale = vlen(objDir);
+        testMinT = minT * scale;
+    } else if (ob.flags & RT_OBJ_HAS_MOTION_BLUR) {
+        to = ro - mk(ob.mbx, ob.mby, ob.mbz) * time;
+    }
+}
+// raytracer.cpp:598-606
+RT_BOX_FN float world_t(const DObject& ob, V3 ro, float time, V3 to, V3 td, float t) {
+    if (!(ob.flags & RT_OBJ_HAS_TRANSFORM)) return t;
+    V3 objHit = to + td * t;
+    V3 worldHit = xf_point(ob.M, objHit);
+    if (ob.flags & RT_OBJ_HAS_MOTION_BLUR) worldHit = worldHit + mk(ob.mbx, ob.mby, ob.mbz) * time;
+    return vlen(worldHit - ro);
+}

@@ -275,32 +275,7 @@ struct HitOut {
     float    beta, gamma;
 };
 
-// Per-object ray set-up, raytracer.cpp:559-587 (and :1070-1095 for shadows).
-__device__ __forceinline__ void object_space_ray(const DObject& ob, V3 ro, V3 rd, float time, float minT, V3& to,
-                                                 V3& td, float& testMinT) {
-    to = ro;
-    td = rd;
-    testMinT = minT;
-    if (ob.flags & RT_OBJ_HAS_TRANSFORM) {
-        V3 o2 = ro;
-        if (ob.flags & RT_OBJ_HAS_MOTION_BLUR) o2 = o2 - mk(ob.mbx, ob.mby, ob.mbz) * time;
-        to = xf_point(ob.Minv, o2);
-        V3 objDir = xf_vector(ob.Minv, rd);
-        td = normalize(objDir);
-        float scale = vlen(objDir);
-        testMinT = minT * scale;
-    } else if (ob.flags & RT_OBJ_HAS_MOTION_BLUR) {
-        to = ro - mk(ob.mbx, ob.mby, ob.mbz) * time;
-    }
-}
-// raytracer.cpp:598-606
-__device__ __forceinline__ float world_t(const DObject& ob, V3 ro, float time, V3 to, V3 td, float t) {
-    if (!(ob.flags & RT_OBJ_HAS_TRANSFORM)) return t;
-    V3 objHit = to + td * t;
-    V3 worldHit = xf_point(ob.M, objHit);
-    if (ob.flags & RT_OBJ_HAS_MOTION_BLUR) worldHit = worldHit + mk(ob.mbx, ob.mby, ob.mbz) * time;
-    return vlen(worldHit - ro);
-}
+// (object_space_ray and world_t, the per-object ray set-up of raytracer.cpp:559-606, are in rt_box.h: host-testable)
 
 __device__ __forceinline__ uint32_t leaf_count(const DScene& S, uint32_t link, bool top) {
     uint32_t c = RT_LEAF_COUNT(link);

@@ -159,6 +159,56 @@ int main() {
     }
     std::printf("triangles / spheres / planes: %llu cases (%llu hits), %llu mismatches\n", pcases, phits, pbad);
     bad += pbad;
+
+    // ---- the per-object ray set-up and the way back to a world distance (raytracer.cpp:559-606): object_space_ray,
+    // world_t against the oracle's, over random affine transforms (non-uniform and negative scales, shears, large
+    // translations), with and without motion blur, on rays of unit and non-unit direction
+    unsigned long long xbad = 0, xcases = 0;
+    {
+        uint64_t st = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (float)((st >> 40) & 0xFFFFFF) / 16777216.0f; };
+        auto sym = [&](float s) { return (rnd() * 2.0f - 1.0f) * s; };
+        for (int k = 0; k < 400000; k++) {
+            DObject ob;
+            std::memset(&ob, 0, sizeof(ob));
+            const float big = (k % 5 == 0) ? 1000.0f : 3.0f;
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) {
+                ob.M[r * 4 + c] = (c == 3) ? sym(big) : sym(2.0f) + ((r == c) ? ((k % 3) ? 1.0f : -1.0f) : 0.0f);
+                ob.Minv[r * 4 + c] = (c == 3) ? sym(big) : sym(2.0f) + ((r == c) ? 1.0f : 0.0f);
+            }
+            ob.M[15] = ob.Minv[15] = 1.0f;
+            ob.mbx = sym(2.0f); ob.mby = sym(2.0f); ob.mbz = sym(2.0f);
+            ob.flags = (uint32_t)(k & 3);             // RT_OBJ_HAS_TRANSFORM = 1, RT_OBJ_HAS_MOTION_BLUR = 2
+            ray_t ray;
+            ray.o = v3{sym(20.0f), sym(20.0f), sym(20.0f)};
+            v3 d = {sym(1.0f), sym(1.0f), sym(1.0f)};
+            if (k % 2) { const float l = std::sqrt(d.x * d.x + d.y * d.y + d.z * d.z) + 1e-9f; d = v3{d.x / l, d.y / l, d.z / l}; }
+            if (k % 17 == 0) d = v3{0.0f, (k % 34) ? 1.0f : -1.0f, 0.0f};
+            ray.d = d;
+            ray.depth = 0;
+            ray.time = rnd();
+            const float minT = (k % 11 == 0) ? FLT_MAX : rnd() * 100.0f;
+            const float mb[3] = {ob.mbx, ob.mby, ob.mbz};
+            ray_t test;
+            float o_minT;
+            orc::ray_ctr rc;
+            std::memset(&rc, 0, sizeof(rc));
+            orc::object_space_ray(&ray, ob.flags, ob.Minv, mb, minT, &test, &o_minT, &rc);
+            V3 to, td;
+            float d_minT;
+            object_space_ray(ob, V3{ray.o.x, ray.o.y, ray.o.z}, V3{ray.d.x, ray.d.y, ray.d.z}, ray.time, minT, to, td, d_minT);
+            const float t = rnd() * 50.0f;
+            const float o_wt = orc::world_t(&ray, &test, t, ob.flags, ob.M, mb);
+            const float d_wt = world_t(ob, V3{ray.o.x, ray.o.y, ray.o.z}, ray.time, to, td, t);
+            xcases++;
+            const bool same = bits(to.x) == bits(test.o.x) && bits(to.y) == bits(test.o.y) && bits(to.z) == bits(test.o.z) &&
+                              bits(td.x) == bits(test.d.x) && bits(td.y) == bits(test.d.y) && bits(td.z) == bits(test.d.z) &&
+                              bits(d_minT) == bits(o_minT) && bits(d_wt) == bits(o_wt);
+            if (!same && xbad++ < 10) std::printf("TRANSFORM MISMATCH case %d flags %u: minT %g / %g, world t %g / %g\n", k, ob.flags, d_minT, o_minT, d_wt, o_wt);
+        }
+    }
+    std::printf("object-space rays / world distances: %llu cases, %llu mismatches\n", xcases, xbad);
+    bad += xbad;
     std::printf("total: %llu mismatches\n", bad);
     return bad ? 1 : 0;
 }
