@@ -261,9 +261,10 @@ enum {
                                    a render allocates four records per sample of its largest chunk, up to this */
     RT_OPT_CHUNK_SAMPLES  = 3,  /* max pixel-samples started per chunk (default 64 M) */
     RT_OPT_STACK_CAP      = 4   /* DIAGNOSTIC: traversal stack entries per ray instead of what the upload derived from the
-                                   scene's BVH depths (>= 64, so that every BVH the reference can walk with its stack[64],
-                                   raytracer.cpp:533,766, fits); tests use it to provoke RT_ERR_OVERFLOW.  0 = derived value
-                                   again at the next rt_update_scene */
+                                   scene's BVH depths (the derived value is >= 64, so that every BVH the reference can walk
+                                   with its stack[64], raytracer.cpp:533,766, fits).  Accepted: 11 .. 4096 (more than the
+                                   entries kept in LDS), values below the derived one make deep rays fail with
+                                   RT_ERR_OVERFLOW — tests use that.  0 = the derived value again, from the next render on */
 };
 
 /* Number of HIP devices visible to this process (<0: rt_status). */
@@ -342,8 +343,8 @@ int rt_render_tile_device(rt_scene* s, const rt_camera_desc* cam,
                           void* d_rgb_out, size_t rgb_row_stride_bytes,
                           void* d_hit_id_out, rt_stats* stats, void* hip_stream);
 
-/* rt_render_tile_device for callers that cannot allocate: HIP-graph capture, tight serving loops, harnesses
- * that forbid hipMalloc.  It has no counterpart in the reference (whose loop allocates nothing but its image,
+/* rt_render_tile_device for callers that cannot allocate: tight serving loops, harnesses that forbid hipMalloc,
+ * HIP-graph capture (see the end of this comment for what can be captured).  It has no counterpart in the reference (whose loop allocates nothing but its image,
  * raytracer.cpp:34).  The call allocates NOTHING — no device or pinned memory, no events: everything a render
  * otherwise keeps in buffers of the scene (control block, traversal spill stacks and donation candidates, the
  * ray-record pool and shadow slots of a chunk, the MT19937 state of multi-sample chunks) lives in one 32 MiB
@@ -355,7 +356,12 @@ int rt_render_tile_device(rt_scene* s, const rt_camera_desc* cam,
  * rt_render_tile_device (no stats); it returns after enqueueing when the scene spawns no child rays and
  * synchronises the stream otherwise (a chunk's pool-overflow check), failures of an early return being reported
  * as there.  All calls on one GPU share that GPU's array, whatever the scene: calls that overlap in time on one
- * GPU (other streams, other threads, other scenes) race — serialise them. */
+ * GPU (other streams, other threads, other scenes) race — serialise them.
+ * Stream capture: a call on a scene WITHOUT reflective materials (no child rays: it only enqueues) may be recorded
+ * with hipStreamBeginCapture on `hip_stream` — call rt_sync() first, so that no earlier render's check is pending —
+ * and replayed with hipGraphLaunch; after synchronising the stream of a replay, rt_sync() reports what that replay's
+ * kernels left (overflow, internal bounds).  A scene with reflective materials synchronises the stream after every
+ * chunk (the pool-overflow check) and cannot be captured; tests/test_zz_no_alloc.py records and replays a graph. */
 int rt_render_tile_device_noalloc(rt_scene* s, const rt_camera_desc* cam,
                                   int x0, int y0, int tile_w, int tile_h,
                                   void* d_rgb_out, size_t rgb_row_stride_bytes,
@@ -375,6 +381,22 @@ int rt_render_tile_rows_device(rt_scene* s, const rt_camera_desc* cam,
                                int row_parts, int row_part,
                                void* d_rgb_out, size_t rgb_row_stride_bytes,
                                void* d_hit_id_out, rt_stats* stats, void* hip_stream);
+
+/* Frame assembly of a multi-GPU render: what follows n calls of rt_render_tile_rows_device(per_gpu[g], cam, x0, y0,
+ * width, height, n, g, d_fb[g], row_stride_bytes, ...) on n replicas of the scene.  d_fb[g] is GPU g's device
+ * frame of the rectangle (height rows of row_stride_bytes, of which it wrote its 8-row bands ty = g, g + n, ...).
+ * GPU g != 0 copies its bands into d_fb[0] — one strided device-to-device copy over its direct xGMI link to GPU 0,
+ * enqueued on hip_streams[g] (NULL array or entry: the scene's own stream), i.e. behind the render enqueued there —
+ * and GPU 0's stream waits for all of them.  host_rgb != NULL: the assembled rectangle is then copied to host_rgb
+ * (height rows of width * 3 bytes, tightly packed; pinned memory preferred) and the call returns when it is there.
+ * host_rgb == NULL: the call returns after enqueueing; d_fb[0] holds the frame for work enqueued later on GPU 0's
+ * stream.  Only RGB8 rows cross the links (north_star: "only the final framebuffer is gathered"); no collective
+ * library is involved — the processes-per-GPU form of the same gather is raytracer_amd/multigpu.py (RCCL).
+ * The reference's counterpart: the one contiguous w*h*3 image its OpenMP team writes (raytracer.cpp:34,82-85) and
+ * stbi_write_png consumes (raytracer.cpp:89).  All scenes may live on one device (rehearsal on a 1-GPU box).
+ * Allocates nothing (events are made at upload). */
+int rt_gather_rows(rt_scene* const* per_gpu, int n, void* const* d_fb, size_t row_stride_bytes,
+                   int width, int height, void* const* hip_streams, uint8_t* host_rgb);
 
 /* Debug aid: copy `count` entries of one array of the ray-record pool, as left
  * by the last render call, to host memory.  which: 0 ray0 (origin.xyz,time; 16 B),

@@ -149,10 +149,13 @@ struct rt_scene {
     // A render that returned before its kernels ran (rt_render_tile_device without stats) leaves its Control block
     // in h_ctl behind ev_async; rt_sync and the next render / update call look at it (check_async).
     hipEvent_t ev_async = nullptr;
+    hipEvent_t ev_gather = nullptr;   // rt_gather_rows: this GPU's bands have been copied into GPU 0's frame
     bool pending_check = false;
+    bool captured_check = false;      // a render was recorded into a HIP graph: its replays leave their Control block in h_ctl
 
     // deepest traversal stack any ray of this scene can need (entries), from the BVH depths found at upload
     uint32_t mesh_stack_need = 0, stack_cap = RT_STACK_MIN_CAP;
+    uint32_t stack_cap_derived = RT_STACK_MIN_CAP;   // what the last upload / update derived from the BVH depths
     uint32_t stack_cap_override = 0;   // RT_OPT_STACK_CAP (diagnostic)
     unsigned char* static_ws = nullptr;   // this GPU's copy of `scratch` (device address)
 };
@@ -662,7 +665,8 @@ int build_top_level(rt_scene* sc, const rt_scene_desc* s) {
     const uint32_t stack_need = stack_need_of_depth(bvh_depth(s->top_nodes, s->n_top_prims ? s->n_top_nodes : 0)) + 1u + sc->mesh_stack_need + 2u;
     if (stack_need > RT_STACK_CAP_LIMIT)
         return fail(RT_ERR_UNSUPPORTED, "BVH too deep: a ray could need %u traversal stack entries (limit %d)", stack_need, RT_STACK_CAP_LIMIT);
-    sc->stack_cap = sc->stack_cap_override ? sc->stack_cap_override : std::max<uint32_t>(RT_STACK_MIN_CAP, stack_need);
+    sc->stack_cap_derived = std::max<uint32_t>(RT_STACK_MIN_CAP, stack_need);
+    sc->stack_cap = sc->stack_cap_override ? sc->stack_cap_override : sc->stack_cap_derived;
     if ((uint64_t)M.n_node_records + nodes.size() >= 0x7FFFFFF0u || top.size() >= RT_LEAF_MAX_FIRST)
         return fail(RT_ERR_UNSUPPORTED, "scene too large for the link encoding (2^26 leaf prims)");
     std::sort(big.begin(), big.end(), [](const DBigLeaf& a, const DBigLeaf& b) { return a.first < b.first; });
@@ -783,9 +787,10 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s, uint32_t upload_fla
 int ensure_pool(rt_scene* sc, uint64_t want_records, uint64_t slack_records = 0, uint64_t slack_shadow = 0) {
     // (slack: the slabs the shading waves of the one-launch pipeline hold but may not fill, rt_mega.h)
     const size_t cap = (size_t)std::min<uint64_t>(sc->opt_pool_records, std::max<uint64_t>(want_records, 1ull << 16) + slack_records);
-    if (sc->pool.cap_records >= cap && sc->pool.cap_records <= sc->opt_pool_records && sc->b_ray0.p) return RT_OK;
     const size_t lights = std::max<uint32_t>(sc->n_point_lights, 1);
     const size_t cap_sh = cap * std::min<size_t>(lights, 4) + (size_t)slack_shadow;
+    // (the shadow slots too: a pool sized by an earlier per-bounce render has no room for the one-launch pipeline's slabs)
+    if (sc->pool.cap_records >= cap && sc->pool.cap_records <= sc->opt_pool_records && sc->pool.cap_shadow >= cap_sh && sc->b_ray0.p) return RT_OK;
     int rc;
     if ((rc = sc->b_ray0.ensure(cap * 16)) || (rc = sc->b_ray1.ensure(cap * 16)) || (rc = sc->b_hit0.ensure(cap * 16)) ||
         (rc = sc->b_hit1.ensure(cap * 8)) || (rc = sc->b_nrm.ensure(cap * 16)) || (rc = sc->b_link.ensure(cap * 16)) ||
@@ -825,10 +830,11 @@ struct Timer {
 // the chunk loop where child rays exist; seen here they mean the pools were too small for what was asked.
 int ctl_status(uint32_t ov, uint32_t stack_cap) {
     if (ov & 8u) return fail(RT_ERR_HIP, "internal: a traced ray reached the wrong lane (rt_ordered.h)");
+    // (a full ring first: the workgroup it stops may also trip the bounds below)
+    if (ov & 64u) return fail(RT_ERR_OVERFLOW, "work ring of a trace workgroup overflowed (rt_mega.h): render smaller tiles or set RT_FLAG_PER_BOUNCE_LAUNCHES");
     if (ov & 32u) return fail(RT_ERR_HIP, "internal: a wave exceeded its round bound (rt_traverse.h)");
     if (ov & 16u) return fail(RT_ERR_HIP, "internal: a ray waited for its helpers beyond the bound (rt_traverse.h)");
     if (ov & 4u) return fail(RT_ERR_OVERFLOW, "traversal stack deeper than %u entries", stack_cap);
-    if (ov & 64u) return fail(RT_ERR_OVERFLOW, "work ring of a trace workgroup overflowed (rt_mega.h): render smaller tiles or set RT_FLAG_PER_BOUNCE_LAUNCHES");
     if (ov & 3u) return fail(RT_ERR_OVERFLOW, "ray pool overflow");
     return RT_OK;
 }
@@ -837,6 +843,12 @@ int ctl_status(uint32_t ov, uint32_t stack_cap) {
 // _rows_device without stats).  Called by rt_sync and at the start of the next render / update of the scene:
 // waits for that render and reports what it left — once; the frame it wrote is not to be trusted then.
 int check_async(rt_scene* sc) {
+    if (sc->captured_check && !sc->pending_check) {
+        // (no event to wait for: the caller has synchronised the stream it launched the graph on — rt.h)
+        const int rc = ctl_status(sc->h_ctl->overflow, sc->stack_cap);
+        if (rc) { const std::string msg = g_err; return fail(rc, "a render of this scene replayed from a HIP graph failed: %s", msg.c_str()); }
+        return RT_OK;
+    }
     if (!sc->pending_check) return RT_OK;
     sc->pending_check = false;
     HIPCHK(hipEventSynchronize(sc->ev_async));
@@ -1167,8 +1179,17 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         // asynchronous return: what the kernels report (stack / shadow-pool overflow, scheduler bounds) is copied
         // behind them and looked at by rt_sync or the next call on this scene (check_async) — never dropped
         HIPCHK(hipMemcpyAsync(sc->h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipEventRecord(sc->ev_async, st));
-        sc->pending_check = true;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (st) (void)hipStreamIsCapturing(st, &cap);
+        if (cap == hipStreamCaptureStatusActive) {
+            // recorded into a graph (rt.h, rt_render_tile_device_noalloc): an event recorded here cannot be waited for
+            // outside the graph; every replay copies its Control block to h_ctl, and rt_sync reads that
+            sc->captured_check = true;
+            sc->h_ctl->overflow = 0;
+        } else {
+            HIPCHK(hipEventRecord(sc->ev_async, st));
+            sc->pending_check = true;
+        }
     }
 #ifdef RT_TIMELINE
     if (want_sync) {
@@ -1351,7 +1372,8 @@ int rt_upload_scene_ex(int device, const rt_scene_desc* scene, uint32_t upload_f
     if (hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess) { delete sc; return fail(RT_ERR_HIP, "hipStreamCreate failed"); }
     if (hipHostMalloc((void**)&sc->h_ctl, sizeof(Control)) != hipSuccess) { rt_free_scene(sc); return fail(RT_ERR_HIP, "hipHostMalloc failed"); }
     if (hipEventCreate(&sc->ev_total_a) != hipSuccess || hipEventCreate(&sc->ev_total_b) != hipSuccess ||
-        hipEventCreateWithFlags(&sc->ev_async, hipEventDisableTiming) != hipSuccess) { rt_free_scene(sc); return fail(RT_ERR_HIP, "hipEventCreate failed"); }
+        hipEventCreateWithFlags(&sc->ev_async, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sc->ev_gather, hipEventDisableTiming) != hipSuccess) { rt_free_scene(sc); return fail(RT_ERR_HIP, "hipEventCreate failed"); }
     rc = guarded([&] { return build_device_scene(sc, scene, upload_flags); });
     if (rc) { rt_free_scene(sc); return rc; }
     if (device < RT_MAX_DEVICES) {
@@ -1410,7 +1432,8 @@ int rt_scene_set_option(rt_scene* s, int option, uint64_t value) {
     case RT_OPT_STACK_CAP:
         if (value != 0 && (value <= RT_STACK_LDS || value > RT_STACK_CAP_LIMIT)) return fail(RT_ERR_INVALID, "stack capacity out of range");
         s->stack_cap_override = (uint32_t)value;
-        if (value) { s->stack_cap = (uint32_t)value; s->ds.stack_cap = s->stack_cap; }
+        s->stack_cap = value ? (uint32_t)value : s->stack_cap_derived;   // 0: the derived capacity again, at once
+        s->ds.stack_cap = s->stack_cap;
         return RT_OK;
     default: return fail(RT_ERR_INVALID, "unknown option %d", option);
     }
@@ -1479,6 +1502,66 @@ int rt_render_tile(rt_scene* s, const rt_camera_desc* cam, int x0, int y0, int t
     return RT_OK;
 }
 
+// The 8-row bands ty = g, g + n, ... of a `rows`-row rectangle as one strided 2-D copy of the full bands plus, for the
+// owner of a shorter last band, one more copy.  pitch = bytes between rows in both buffers, row_bytes = bytes copied per row.
+static hipError_t copy_bands(void* dst, const void* src, size_t pitch, size_t row_bytes, int rows, int n, int g, hipStream_t st) {
+    const int bands_all = (rows + 7) / 8;
+    if (g >= bands_all) return hipSuccess;
+    const int mine = (bands_all - g + n - 1) / n;
+    const bool last_is_mine = (bands_all - 1) % n == g;
+    const int last_rows = rows - (bands_all - 1) * 8;               // 1..8
+    const int full = (last_is_mine && last_rows < 8) ? mine - 1 : mine;
+    hipError_t e = hipSuccess;
+    if (row_bytes == pitch) {
+        // rows are contiguous: a band is one run of 8 rows, the GPU's bands one 2-D copy with a pitch of n bands
+        const size_t band = 8 * pitch;
+        if (full > 0) e = hipMemcpy2DAsync((char*)dst + (size_t)g * band, (size_t)n * band, (const char*)src + (size_t)g * band, (size_t)n * band, band, (size_t)full, hipMemcpyDeviceToDevice, st);
+    } else {
+        for (int b = 0; b < full && e == hipSuccess; b++) {
+            const size_t off = (size_t)(g + b * n) * 8 * pitch;
+            e = hipMemcpy2DAsync((char*)dst + off, pitch, (const char*)src + off, pitch, row_bytes, 8, hipMemcpyDeviceToDevice, st);
+        }
+    }
+    if (e == hipSuccess && full < mine) {
+        const size_t off = (size_t)(bands_all - 1) * 8 * pitch;
+        e = hipMemcpy2DAsync((char*)dst + off, pitch, (const char*)src + off, pitch, row_bytes, (size_t)last_rows, hipMemcpyDeviceToDevice, st);
+    }
+    return e;
+}
+
+int rt_gather_rows(rt_scene* const* per_gpu, int n, void* const* d_fb, size_t row_stride_bytes, int width, int height,
+                   void* const* hip_streams, uint8_t* host_rgb) {
+    if (!per_gpu || !d_fb || n < 1) return fail(RT_ERR_INVALID, "rt_gather_rows: NULL arrays or n < 1");
+    if (width <= 0 || height <= 0 || row_stride_bytes < (size_t)width * 3) return fail(RT_ERR_INVALID, "rt_gather_rows: bad rectangle / stride");
+    for (int g = 0; g < n; g++)
+        if (!per_gpu[g] || !d_fb[g]) return fail(RT_ERR_INVALID, "rt_gather_rows: scene or frame %d is NULL", g);
+    return guarded([&]() -> int {
+        rt_scene* s0 = per_gpu[0];
+        hipStream_t st0 = (hip_streams && hip_streams[0]) ? (hipStream_t)hip_streams[0] : s0->stream;
+        const size_t row_bytes = (size_t)width * 3;
+        for (int g = 1; g < n; g++) {
+            rt_scene* sg = per_gpu[g];
+            hipStream_t st = (hip_streams && hip_streams[g]) ? (hipStream_t)hip_streams[g] : sg->stream;
+            HIPCHK(hipSetDevice(sg->device));
+            if (sg->device != s0->device) {
+                // direct writes into GPU 0's memory (xGMI); "already enabled" is fine, "not possible" leaves the copy to the runtime's staging
+                const hipError_t pe = hipDeviceEnablePeerAccess(s0->device, 0);
+                if (pe != hipSuccess) (void)hipGetLastError();
+            }
+            const hipError_t e = copy_bands(d_fb[0], d_fb[g], row_stride_bytes, row_bytes, height, n, g, st);
+            if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_gather_rows: copy of GPU %d's rows failed: %s", g, hipGetErrorString(e));
+            HIPCHK(hipEventRecord(sg->ev_gather, st));
+        }
+        HIPCHK(hipSetDevice(s0->device));
+        for (int g = 1; g < n; g++) HIPCHK(hipStreamWaitEvent(st0, per_gpu[g]->ev_gather, 0));
+        if (host_rgb) {
+            HIPCHK(hipMemcpy2DAsync(host_rgb, row_bytes, d_fb[0], row_stride_bytes, row_bytes, (size_t)height, hipMemcpyDeviceToHost, st0));
+            HIPCHK(hipStreamSynchronize(st0));
+        }
+        return RT_OK;
+    });
+}
+
 int rt_debug_fetch(rt_scene* s, int which, uint64_t first, uint64_t count, void* out) {
     if (!s || !out) return fail(RT_ERR_INVALID, "NULL argument");
     const DevBuf* b[7] = {&s->b_ray0, &s->b_ray1, &s->b_hit0, &s->b_nrm, &s->b_link, &s->b_color, &s->b_shadow_lit};
@@ -1508,7 +1591,7 @@ void rt_free_scene(rt_scene* s) {
         b->release();
     for (auto& e : s->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    for (hipEvent_t e : {s->ev_total_a, s->ev_total_b, s->ev_async}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {s->ev_total_a, s->ev_total_b, s->ev_async, s->ev_gather}) if (e) (void)hipEventDestroy(e);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     if (s->h_stage) (void)hipHostFree(s->h_stage);
     if (s->stream) (void)hipStreamDestroy(s->stream);

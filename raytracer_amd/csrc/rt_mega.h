@@ -290,7 +290,9 @@ struct MegaIO {
         bool ring_full = false;
         if (!pool_full && n_children && !ring_reserve(false, n_children, lane, cpos)) ring_full = true;
         if (!pool_full && !ring_full && n_slots && !ring_reserve(true, n_slots, lane, apos)) ring_full = true;
-        if (ring_full && lane == 0) atomicOr(&ctl->overflow, 64u);
+        // (a failed reservation leaves `alloc` advanced and never commits, so the next commit on that ring would wait for a
+        // tail that cannot move: stop the workgroup here — the render fails with RT_ERR_OVERFLOW, not with a spin bound)
+        if (ring_full) { if (lane == 0) atomicOr(&ctl->overflow, 64u); abort(); }
         const bool produce = !pool_full && !ring_full;
         if (produce) { rec_next += n_children; sh_next += n_slots; }
         if (valid) {
@@ -432,6 +434,11 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) k_trace_mega(DSc
 // k_combine for the one-launch pipeline: the records of depth `gen` are wherever the waves put them, so every
 // record slot [0, n_records) is looked at and the ones of other depths (and never-used slab slots) are skipped.
 __global__ void __launch_bounds__(256) k_combine_mega(DScene S, Pool P, Control* ctl, int gen, uint32_t n_primary) {
+    // A launch that overflowed a pool or a ring, or was aborted, leaves record slots that nobody wrote (the tail of a slab
+    // reservation that crossed the cap, children that were allocated and never traced): their link / normal / colour
+    // words are whatever the buffers held, and trusting them means reading materials[garbage].  The chunk is redone or
+    // the render fails (render_impl), so nothing is combined.
+    if (ctl->overflow != 0u) return;
     const uint32_t end = min(ctl->n_records, P.cap_records);
     const uint32_t begin = gen == 0 ? 0u : n_primary, stop = gen == 0 ? n_primary : end;     // depth 0 = the primaries, nothing else
     for (uint32_t r = begin + blockIdx.x * blockDim.x + threadIdx.x; r < stop; r += gridDim.x * blockDim.x) {

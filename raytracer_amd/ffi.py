@@ -340,6 +340,8 @@ def hip_lib():
                                      C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Stats)]
         L.rt_render_tile_device.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Stats), C.c_void_p]
+        L.rt_gather_rows.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int,
+                                     C.POINTER(C.c_void_p), C.c_void_p]
         L.rt_render_tile_rows_device.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_int, C.c_int,
                                                  C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Stats),
                                                  C.c_void_p]
@@ -418,6 +420,17 @@ class DeviceScene:
 
     def sync(self):
         _check(hip_lib().rt_sync(self._h))
+
+    @staticmethod
+    def gather_rows(scenes, d_fb_ptrs, row_stride, width, height, host_rgb=None, streams=None):
+        """rt_gather_rows: the bands scene g of n rendered into its own device frame d_fb_ptrs[g] are brought together in
+        d_fb_ptrs[0] (peer copies) and, with host_rgb (a C-contiguous uint8 numpy array of height x width x 3), on the host."""
+        n = len(scenes)
+        hs = (C.c_void_p * n)(*[s._h for s in scenes])
+        fb = (C.c_void_p * n)(*[C.c_void_p(p) for p in d_fb_ptrs])
+        st = (C.c_void_p * n)(*[C.c_void_p(p) for p in streams]) if streams else None
+        out = host_rgb.ctypes.data_as(C.c_void_p) if host_rgb is not None else None
+        _check(hip_lib().rt_gather_rows(hs, n, fb, row_stride, width, height, st, out))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -252,22 +252,17 @@ static bool render_frame_hip(std::vector<Gpu>& gpus, const rt_camera_desc& cam, 
             if (!ok[g]) return;
             // hit ids are a debugging output: straight to the host, band by band in one strided copy
             if (hits && copy_bands(hits, G.d_hits, (size_t)W * 8, H, n, g, hipMemcpyDeviceToHost, G.stream) != hipSuccess) { G.err = "copy of the hit ids failed"; ok[g] = 0; return; }
-            // this GPU's bands into GPU 0's frame: one strided device-to-device copy over the direct xGMI link
-            if (g != 0 && copy_bands(gpus[0].d_fb, G.d_fb, row, H, n, g, hipMemcpyDeviceToDevice, G.stream) != hipSuccess) { G.err = "peer copy of the rows failed"; ok[g] = 0; return; }
-            if (hipEventRecord(G.sent, G.stream) != hipSuccess) { G.err = "hipEventRecord failed"; ok[g] = 0; }
         });
     for (auto& t : th_gpu) t.join();
     for (int g = 0; g < n; g++)
         if (!ok[g]) return false;
-    // GPU 0: wait for every peer's rows, then the whole frame to the host in one copy
+    // frame assembly (rt.h): every GPU's bands into GPU 0's frame — one strided device-to-device copy per GPU over its
+    // direct xGMI link, behind its render on its stream — and the whole frame to the host in one copy
     Gpu& G0 = gpus[0];
-    if (hipSetDevice(G0.device) != hipSuccess) { G0.err = "hipSetDevice failed"; return false; }
-    for (int g = 1; g < n; g++)
-        if (hipStreamWaitEvent(G0.stream, gpus[g].sent, 0) != hipSuccess) { G0.err = "hipStreamWaitEvent failed"; return false; }
-    if (hipMemcpyAsync(image, G0.d_fb, fb_bytes, hipMemcpyDeviceToHost, G0.stream) != hipSuccess || hipStreamSynchronize(G0.stream) != hipSuccess) {
-        G0.err = "copy of the frame to the host failed";
-        return false;
-    }
+    std::vector<rt_scene*> scenes(n);
+    std::vector<void*> fbs(n), streams(n);
+    for (int g = 0; g < n; g++) { scenes[g] = gpus[g].scene; fbs[g] = gpus[g].d_fb; streams[g] = (void*)gpus[g].stream; }
+    if (rt_gather_rows(scenes.data(), n, fbs.data(), row, W, H, streams.data(), image) != RT_OK) { G0.err = rt_last_error(); return false; }
     for (int g = 1; g < n && hits; g++)
         if (hipStreamSynchronize(gpus[g].stream) != hipSuccess) { gpus[g].err = "stream sync failed"; return false; }
     render_s = now_s() - a;

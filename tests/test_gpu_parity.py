@@ -164,6 +164,21 @@ def test_one_launch_and_per_bounce_pipelines_agree(rt):
     ds.close()
     assert st.launches_shadow == 0 and st.chunks > 1
     assert (a == b).all()
+    # the same on a pool that is re-made over buffers another render has just filled and freed: a chunk that overflows
+    # leaves record slots nobody wrote, and what they hold is then stale records of the earlier layout — nothing may be
+    # combined from them (k_combine_mega), and a pool sized by a per-bounce render is re-made for the slabs' shadow slots
+    ds = rt.DeviceScene(hs, 0)
+    ds.set_option(rt.RT_OPT_FLAGS, rt.RT_FLAG_PER_BOUNCE_LAUNCHES)
+    c, _ = ds.render(cam)
+    ds.set_option(rt.RT_OPT_POOL_RECORDS, 600000)
+    ds.set_option(rt.RT_OPT_FLAGS, rt.RT_FLAG_ONE_LAUNCH | rt.RT_FLAG_TIMING)
+    st = rt.Stats()
+    d, _ = ds.render(cam, stats=st)
+    ds.set_option(rt.RT_OPT_FLAGS, rt.RT_FLAG_PER_BOUNCE_LAUNCHES)
+    e, _ = ds.render(cam)
+    ds.close()
+    assert st.launches_shadow == 0 and st.chunks > 1
+    assert (c == a).all() and (d == a).all() and (e == a).all()
 
 
 def test_ragged_sizes_and_tiny_images(rt):
@@ -220,6 +235,45 @@ def test_tiles_and_interleaved_rows_stitch_to_the_full_frame(rt):
         assert (fb[other] == 7).all()          # rows of other ranks are left untouched
     ds.close()
     assert (merged.cpu().numpy() == full).all()
+
+
+def test_gather_rows_assembles_the_frame_of_three_replicas(rt):
+    """rt_gather_rows (include/rt.h), the frame assembly of a multi-GPU render, rehearsed with three replicas of the
+    scene on one GPU: each renders its interleaved 8-row bands into its own device frame on its own stream, the call
+    brings the bands together in replica 0's frame and on the host — byte-equal to a single call's frame; with a frame
+    whose height is not a multiple of 8 (a short last band), with padded rows, and device-only (host_rgb NULL)."""
+    import numpy as np
+    import torch
+    for hs, (W, H) in ((util.golden_scene("hw1_cornellbox_recursive"), (800, 800)), (rt.scenes.spheres_scene(203, 149).build(), (203, 149))):
+        cam = hs.camera(0)
+        ref = rt.DeviceScene(hs, 0)
+        full, _ = ref.render(cam)
+        ref.close()
+        for n, pad in ((3, 0), (2, 40), (5, 0)):
+            stride = W * 3 + pad
+            scenes = [rt.DeviceScene(hs, 0) for _ in range(n)]
+            streams = [torch.cuda.Stream() for _ in range(n)]
+            fbs = [torch.full((H, stride), 9 + g, dtype=torch.uint8, device="cuda:0") for g in range(n)]
+            for g in range(n):
+                scenes[g].render_rows_device(cam, 0, 0, W, H, n, g, fbs[g].data_ptr(), stride, stream=streams[g].cuda_stream)
+            host = np.zeros((H, W, 3), dtype=np.uint8)
+            rt.DeviceScene.gather_rows(scenes, [f.data_ptr() for f in fbs], stride, W, H, host_rgb=host, streams=[s.cuda_stream for s in streams])
+            assert (host == full).all(), (n, pad)
+            assert (fbs[0][:, :W * 3].cpu().numpy().reshape(H, W, 3) == full).all()
+            if pad:
+                assert (fbs[0][:, W * 3:] == 9).all()                # the padding of GPU 0's rows is not written
+            # device-only form: the frame is in replica 0's buffer for work enqueued on its stream afterwards
+            fbs[0].fill_(1)
+            torch.cuda.synchronize()
+            scenes[0].render_rows_device(cam, 0, 0, W, H, n, 0, fbs[0].data_ptr(), stride, stream=streams[0].cuda_stream)
+            rt.DeviceScene.gather_rows(scenes, [f.data_ptr() for f in fbs], stride, W, H, streams=[s.cuda_stream for s in streams])
+            with torch.cuda.stream(streams[0]):
+                copy = fbs[0].clone()
+            streams[0].synchronize()
+            assert (copy[:, :W * 3].cpu().numpy().reshape(H, W, 3) == full).all()
+            for s_ in scenes:
+                s_.sync()
+                s_.close()
 
 
 def test_full_size_properties_mesh1m(rt):

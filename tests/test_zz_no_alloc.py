@@ -65,3 +65,59 @@ def test_no_alloc_entry_point_equals_render_tile_device():
     dsg.close()
     _both(rt, ds, hs.camera(0), 0, 0, 512, 288)                      # refused calls left nothing behind
     ds.close()
+
+
+def test_no_alloc_entry_point_allocates_nothing_and_can_be_captured_in_a_hip_graph():
+    """What defines the entry point: device memory in use does not move across its calls (child rays, multi-sample and
+    depth-0 scenes), and a depth-0 call can be recorded with stream capture in the mode that turns every allocation
+    into an error, replayed, and gives rt_render_tile_device's bytes."""
+    import torch
+    import raytracer_amd as rt
+    rt.hip_lib()
+    dev = "cuda:0"
+    cases = [(rt.scenes.instanced_scene(grid=64, width=640, height=400), (16, 0, 600, 400)),
+             (rt.scenes.spheres_scene(200, 150, num_samples=16, dof=True), (0, 0, 200, 150)),
+             (rt.scenes.mesh_scene(grid=128, width=512, height=288), (0, 0, 512, 288))]
+    for spec, (x0, y0, w, h) in cases:
+        hs = spec.build()
+        cam = hs.camera(0)
+        ds = rt.DeviceScene(hs, 0)
+        out = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
+        hits = torch.zeros((h, w, 2), dtype=torch.int32, device=dev)
+        ds.render_device_noalloc(cam, x0, y0, w, h, out.data_ptr(), w * 3, d_hits_ptr=hits.data_ptr())   # warm-up (code object, first touch)
+        ds.sync()
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        for _ in range(3):
+            ds.render_device_noalloc(cam, x0, y0, w, h, out.data_ptr(), w * 3, d_hits_ptr=hits.data_ptr())
+            ds.render_device_noalloc(cam, x0 + 8, y0 + 8, w // 2, h // 2, out.data_ptr(), w * 3)
+        ds.sync()
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        assert free1 == free0, f"device memory in use moved by {free0 - free1} bytes across no-allocation calls"
+        ds.close()
+    # stream capture, depth-0 scene (the last one built above): global capture mode = any hipMalloc / synchronisation fails
+    hs = cases[2][0].build()
+    cam = hs.camera(0)
+    ds = rt.DeviceScene(hs, 0)
+    w, h = 512, 288
+    ref = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
+    ds.render_device(cam, 0, 0, w, h, ref.data_ptr(), w * 3, stats=rt.Stats())
+    out = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
+    ds.render_device_noalloc(cam, 0, 0, w, h, out.data_ptr(), w * 3)     # (nothing left to set up inside the capture)
+    ds.sync()
+    out.zero_()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s, capture_error_mode="global"):
+        ds.render_device_noalloc(cam, 0, 0, w, h, out.data_ptr(), w * 3, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(out.sum().item()) == 0, "recording a graph must not run anything"
+    for _ in range(2):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        ds.sync()                                                          # reports what the replay's kernels left
+        assert torch.equal(out, ref)
+    ds.close()
