@@ -114,7 +114,7 @@ class Run:
         from raytracer_amd import multigpu
         e = self.env
         self.ds.render_rows_device(self.cam, 0, 0, self.W, self.H, e.world, e.rank, self.fb.data_ptr(), self.W * 3, stats=st, stream=e.stream)
-        return multigpu.gather_frame(self.fb, e.rank, e.world)
+        return multigpu.gather_frame(self.fb, e.rank, e.world, force=e.dist)
 
     def timed(self, steps, warmup):
         import torch
@@ -141,7 +141,7 @@ class Run:
         elapsed = time.perf_counter() - t0
         t = torch.tensor([elapsed], dtype=torch.float64, device=e.dev)
         r = torch.tensor(rays, dtype=torch.float64, device=e.dev)
-        if e.world > 1:
+        if e.dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)          # the slowest rank's clock
             dist.all_reduce(r, op=dist.ReduceOp.SUM)          # rays of all ranks
         return {"elapsed": float(t.item()), "rays_frame": [float(v) for v in r.tolist()], "rays_rank": rays, "acc": acc,
@@ -153,6 +153,31 @@ class Run:
 
 class Env:
     pass
+
+
+def frame_sha16(frame):
+    """Identity of a frame (RGB8 bytes, row-major): equal for every N, since pixels are seeded by their global
+    coordinates — the N = 1 line carries it for the strong-scaling workload, every N > 1 line for the gathered frame."""
+    return hashlib.sha256(frame.contiguous().cpu().numpy().tobytes()).hexdigest()[:16]
+
+
+def share_projection(run, ns=(1, 2, 4, 8), reps=3):
+    """One rank's share of the strong-scaling frame on THIS GPU for N = 1, 2, 4, 8 (rank 0's interleaved bands, no
+    gather): the time an N-GPU frame cannot beat, i.e. the ceiling of the scaling curve set by the per-launch tails."""
+    from raytracer_amd import Stats
+    out = {"n": [], "share_ms": [], "speedup_ceiling": []}
+    base = None
+    for n in ns:
+        best = None
+        for _ in range(reps):
+            st = Stats()
+            run.ds.render_rows_device(run.cam, 0, 0, run.W, run.H, n, 0, run.fb.data_ptr(), run.W * 3, stats=st, stream=run.env.stream)
+            best = st.ms_total if best is None else min(best, st.ms_total)
+        base = best if base is None else base
+        out["n"].append(n)
+        out["share_ms"].append(best)
+        out["speedup_ceiling"].append(base / best)
+    return out
 
 
 def pmc_block(workload_key, kernel):
@@ -198,7 +223,38 @@ def roofline_single(acc, rays, wb, workload_key):
     # what binds instead (VALU issue at partial lane occupancy): from the PMC passes, same condition as `traffic`
     for k in ("valu_issue_util", "waves_per_simd", "lane_occupancy", "l2_hit_rate", "valu_insts_per_launch"):
         r[k] = pm.get(k) if pm else None
+    # The roof that binds.  The trace loop issues one wave64 VALU instruction per SIMD every 4 cycles at best; what the
+    # chip's FP32 lanes deliver is that issue rate times the lanes each instruction has switched on.
+    r["binding"] = binding_block(pm)
+    # An HBM fraction above 1 is not a measurement error: the bytes are those of the REFERENCE's traversal
+    # and a kernel that does less work than that traversal (any-hit exit) moves fewer.  Such a figure ranks nothing.
+    r["saturated"] = bool(ach / HBM_PEAK_GBS > 1.0)
+    oth = r["other_kernel"]
+    if oth["achieved"] is not None:
+        oth["frac"] = oth["achieved"] / HBM_PEAK_GBS
+        oth["saturated"] = bool(oth["frac"] > 1.0)
+        oth["binding"] = binding_block(pmc_block(workload_key, oth["kernel"]))
     return r, bytes_closest
+
+
+FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 vector peak
+
+
+def binding_block(pm):
+    """VALU issue at partial lane occupancy, from the committed PMC passes (null when taken on other sources)."""
+    if not pm or pm.get("valu_issue_util") is None or pm.get("lane_occupancy") is None:
+        return None
+    useful = pm["valu_issue_util"] * pm["lane_occupancy"]
+    b = {"bound": "valu_issue", "achieved": useful * FP32_PEAK_TFLOPS, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s-equivalent lanes",
+         "frac": useful, "valu_issue_util": pm["valu_issue_util"], "lane_occupancy": pm["lane_occupancy"],
+         "waves_per_simd": pm.get("waves_per_simd")}
+    if pm.get("SQ_INSTS_SALU") and pm.get("SQ_INSTS_VALU"):
+        b["salu_per_valu"] = pm["SQ_INSTS_SALU"] / pm["SQ_INSTS_VALU"]
+        b["salu_insts_per_launch"] = pm["SQ_INSTS_SALU"]
+        b["valu_insts_per_launch"] = pm["SQ_INSTS_VALU"]
+    if pm.get("trace_avg_ms") is not None:
+        b["rocprof_avg_launch_ms"] = pm["trace_avg_ms"]
+    return b
 
 
 def roofline_all_traces(acc, rays_rank, wb, steps):
@@ -232,6 +288,10 @@ def main():
     e.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if e.world != args.gpus and e.world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={e.world}")
+    # RT_BENCH_FORCE_DIST=1 (tests/test_gpu_frames.py, never the driver): take the N > 1 branch with whatever world size
+    # the launcher gave — with one rank that is a one-rank RCCL communicator, so RCCL initialisation, the barrier, the
+    # all-reduces and the gather of uint8 rows all execute on a box with a single GPU.
+    e.dist = e.world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     # Rehearsal on a 1-GPU box: RT_BENCH_REHEARSE=1 puts every rank on GPU 0 and uses gloo (RCCL refuses two
@@ -243,7 +303,7 @@ def main():
         faulthandler.dump_traceback_later(150, exit=True)   # a rehearsal that stalls says where
     torch.cuda.set_device(e.local_rank)
     e.dev = torch.device("cuda", e.local_rank)
-    if e.world > 1:
+    if e.dist:
         if rehearse:
             dist.init_process_group("gloo")
         else:
@@ -252,7 +312,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if e.world > 1:
+        if e.dist:
             dist.barrier()
             torch.cuda.synchronize()
     e.fence = fence
@@ -262,7 +322,7 @@ def main():
     strong_w, strong_h = (STRONG_W, STRONG_H) if args.grid == 709 else (1920, 1080)   # (--grid: rehearsals at a smaller size)
     line = None
 
-    if e.world == 1:
+    if not e.dist:
         # ------------------------------------------------------------------ N = 1: configs[1]
         spec = scenes.mesh_scene(args.grid, 1920, 1080)
         run = Run(e, spec)
@@ -321,7 +381,10 @@ def main():
                 "value": sum(x["rays_frame"]) / (x["elapsed"] / k) / 1e6, "unit": "Mrays/s", "n_gpus": 1, "steps": k,
                 "ms_per_step": x["elapsed"] / k * 1e3, "seconds_per_frame": x["elapsed"] / k, "rays_per_frame": sum(x["rays_frame"]),
                 "trace_launches_per_frame": n_launch / k,
-                "trace_achieved_GBps": bts / dur / 1e9 if dur > 0 else None, "trace_frac_of_hbm_peak": bts / dur / 1e9 / HBM_PEAK_GBS if dur > 0 else None}
+                "trace_achieved_GBps": bts / dur / 1e9 if dur > 0 else None, "trace_frac_of_hbm_peak": bts / dur / 1e9 / HBM_PEAK_GBS if dur > 0 else None,
+                "frame_sha16": frame_sha16(x["frame"])}
+            # one rank's share of that frame for N = 1, 2, 4, 8 on this GPU: what the per-launch tails leave of ideal scaling
+            line["strong_scaling_projection"] = share_projection(rs)
             rs.close()
         if not args.no_cpu:
             cb, parity = cpu_baseline(spec, exact_frame.cpu().numpy())
@@ -338,6 +401,7 @@ def main():
         ms_per_step = res["elapsed"] / args.steps * 1e3
         value = rays_per_frame / (res["elapsed"] / args.steps) / 1e6
         n_launch, dur, bts = roofline_all_traces(res["acc"], res["rays_rank"], wb_all["inst10_7680x4320"], args.steps)
+        sha = frame_sha16(res["frame"]) if e.rank == 0 else None       # the gathered frame (equal to the one-GPU frame's)
         run.close()
         weak = None
         if not args.no_extras:
@@ -357,7 +421,8 @@ def main():
                 "config": {"workload": f"inst10: 10 instances of the {2 * (args.grid - 1) ** 2}-triangle mesh (mirror / dielectric / conductor), {strong_w}x{strong_h}, 1 spp, depth 6 (BASELINE configs[4])",
                            "rays_per_frame": rays_per_frame, "seconds_per_frame": ms_per_step / 1e3,
                            "partition": f"fixed frame; interleaved 8-row bands over {e.world} GPUs, scene replicated, RGB8 rows gathered to rank 0 (one gather, {strong_w * strong_h * 3} bytes in all)",
-                           "single_gpu_figure": "the N = 1 line's strong_scaling_base is this workload on one GPU"},
+                           "single_gpu_figure": "the N = 1 line's strong_scaling_base is this workload on one GPU",
+                           "frame_sha16": sha, "gather": "gloo (rehearsal)" if rehearse else "rccl"},
                 "roofline": {"bound": "hbm", "kernel": "all trace launches of rank 0 (k_trace_closest, k_trace_mixed per bounce, k_trace_shadow)",
                              "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                              "launches_per_frame": n_launch / args.steps, "avg_launch_ms": dur * 1e3 / max(n_launch, 1),
@@ -369,7 +434,7 @@ def main():
                 line["weak"] = weak
     if e.rank == 0 and line is not None:
         print(json.dumps(line), flush=True)
-    if e.world > 1:
+    if e.dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -77,3 +77,31 @@ def test_resident_scene_pipeline_multi_gpu_bands_and_tiles(tmp_path):
             got = np.array(Image.open(out / p).convert("RGB"))
             assert (got == want[f]).all(), (name, f, int((got != want[f]).any(-1).sum()))
         print(name, json.dumps(lines[-1]))
+
+
+def test_bench_multi_gpu_branch_runs_over_rccl_with_one_rank():
+    """bench.py's N > 1 branch (strong-scaling frame, barrier, all-reduces of the clocks and ray counts, gather of the
+    RGB8 rows to rank 0) launched as the driver launches it — python -m torch.distributed.run, backend nccl = RCCL —
+    with ONE rank (RT_BENCH_FORCE_DIST=1: a one-rank communicator, the gather not short-circuited), so that RCCL
+    initialisation and a dist.gather of uint8 rows execute on real hardware on a 1-GPU box.  The gathered frame's
+    checksum in the line must be that of the same frame rendered directly."""
+    import hashlib
+    import sys
+    import raytracer_amd as rt
+    env = dict(os.environ, RT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    env.pop("RT_BENCH_REHEARSE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--grid", "96", "--no-extras"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["config"]["gather"] == "rccl"
+    assert line["value"] > 0 and line["steps"] == 2
+    hs = rt.scenes.instanced_scene(96, 1920, 1080).build()      # (--grid 96: the strong-scaling frame at its rehearsal size)
+    ds = rt.DeviceScene(hs, 0)
+    rgb, _ = ds.render(hs.camera(0))
+    ds.close()
+    assert line["config"]["frame_sha16"] == hashlib.sha256(np.ascontiguousarray(rgb).tobytes()).hexdigest()[:16]
+    assert abs(line["config"]["rays_per_frame"] - 0) > 0

@@ -362,35 +362,44 @@ def test_full_size_properties_inst10_8k_config4(rt, inst10_full):
 
 
 def test_full_size_properties_inst10_4k_64spp_config3(rt, inst10_full):
-    """BASELINE configs[3] at its real size: 3840x2160 at 64 spp, depth 6, on a 512-row band — 125.8 M primary
-    samples, more than one chunk of the default 64 M, so the multi-chunk MT19937 scratch and a 27 GB record pool
-    are what runs.  The band must not depend on how it is chunked (a second render with 16 M-sample chunks), the
-    primary-ray count is samples x pixels, and a window of it equals the oracle's (bytes and ids)."""
+    """BASELINE configs[3] at its real size, WHOLE frame: 3840x2160 at 64 spp, depth 6 — 530.8 M primary samples in
+    eight chunks of the default 64 M, the multi-chunk MT19937 scratch and a 27 GB record pool.  Ray-count identities
+    of the frame; a 512-row band rendered on its own, with 16 M-sample chunks, must equal the frame's rows (a pixel
+    does not depend on the call's rectangle nor on how it is chunked) and its counts must not depend on the chunking;
+    two windows that lie in different chunks of the frame equal the oracle's (bytes and ids)."""
     import torch
     from oracle import binding as ob
     hs = inst10_full
     hs.set_camera_resolution(0, 3840, 2160, 64)
     cam = hs.camera(0)
     assert cam.num_samples == 64 and cam.samples_per_side == 8
-    W, y0, bh = 3840, 824, 512
+    W, H = 3840, 2160
     dev = "cuda:0"
     ds = rt.DeviceScene(hs, 0)
+    fb = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+    hf = torch.zeros((H, W, 2), dtype=torch.int32, device=dev)
+    sf = rt.Stats()
+    ds.render_device(cam, 0, 0, W, H, fb.data_ptr(), W * 3, d_hits_ptr=hf.data_ptr(), stats=sf)
+    assert sf.chunks >= 8 and sf.rays_primary == W * H * 64
+    assert sf.rays_secondary > 0 and sf.rays_shadow > sf.rays_primary            # depth 6: children; two lights per lit hit
+    y0, bh = 824, 512
     a = torch.zeros((bh, W, 3), dtype=torch.uint8, device=dev)
-    ha = torch.zeros((bh, W, 2), dtype=torch.int32, device=dev)
     sa = rt.Stats()
-    ds.render_device(cam, 0, y0, W, bh, a.data_ptr(), W * 3, d_hits_ptr=ha.data_ptr(), stats=sa)
+    ds.render_device(cam, 0, y0, W, bh, a.data_ptr(), W * 3, stats=sa)
     assert sa.chunks > 1 and sa.rays_primary == W * bh * 64
     ds.set_option(rt.RT_OPT_CHUNK_SAMPLES, 16 << 20)
     b = torch.zeros_like(a)
     sb = rt.Stats()
     ds.render_device(cam, 0, y0, W, bh, b.data_ptr(), W * 3, stats=sb)
     ds.close()
-    assert sb.chunks >= 7 and torch.equal(a, b)
+    assert sb.chunks >= 7 and torch.equal(a, b) and torch.equal(a, fb[y0:y0 + bh])
     assert [sa.rays_primary, sa.rays_secondary, sa.rays_shadow] == [sb.rays_primary, sb.rays_secondary, sb.rays_shadow]
-    x0, wy, ww, wh = 1856, y0 + 224, 64, 40
-    o_rgb, o_hits, _ = ob.render(hs, cam, x0=x0, y0=wy, w=ww, h=wh, want_hits=True)
-    assert (a[wy - y0:wy - y0 + wh, x0:x0 + ww].cpu().numpy() == o_rgb).all()
-    assert (ha[wy - y0:wy - y0 + wh, x0:x0 + ww].cpu().numpy().view(np.uint32) == o_hits).all()
+    # the frame's chunks are runs of 8-row tile rows of about 270 rows each: the windows lie in the fourth and the sixth
+    for (x0, wy, ww, wh) in ((1856, 1048, 64, 40), (1200, 1500, 48, 32)):
+        o_rgb, o_hits, _ = ob.render(hs, cam, x0=x0, y0=wy, w=ww, h=wh, want_hits=True)
+        assert (fb[wy:wy + wh, x0:x0 + ww].cpu().numpy() == o_rgb).all()
+        assert (hf[wy:wy + wh, x0:x0 + ww].cpu().numpy().view(np.uint32) == o_hits).all()
+        assert (o_hits[..., 0] != 0xFFFFFFFF).any()
     hs.set_camera_resolution(0, 7680, 4320, 1)
 
 

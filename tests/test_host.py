@@ -131,28 +131,33 @@ sys.path.insert(0, sys.argv[1])
 from raytracer_amd import multigpu
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
-H, W = 52, 24
-want = (torch.arange(H * W * 3, dtype=torch.int64).reshape(H, W, 3) % 251).to(torch.uint8)
-fb = torch.full((H, W, 3), 255, dtype=torch.uint8)           # garbage in rows this rank does not own
-mine = multigpu.rows_of(rank, world, H)
-fb[mine] = want[mine]
-out = multigpu.gather_frame(fb, rank, world)
+W = 24
+for H in (52, 48, 8, 16, 4320 // 8):          # ragged last band (index path); whole bands (strided views); fewer bands than ranks
+    want = (torch.arange(H * W * 3, dtype=torch.int64).reshape(H, W, 3) % 251).to(torch.uint8)
+    for rep in range(2):                      # the plan and its buffers are reused
+        fb = torch.full((H, W, 3), 255, dtype=torch.uint8)           # garbage in rows this rank does not own
+        mine = multigpu.rows_of(rank, world, H)
+        fb[mine] = want[mine]
+        out = multigpu.gather_frame(fb, rank, world)
+        if rank == 0:
+            assert out is not None and torch.equal(out, want), f"merged frame differs (H={H})"
+        else:
+            assert out is None
 if rank == 0:
-    assert out is not None and torch.equal(out, want), "merged frame differs"
     print("MERGE_OK")
-else:
-    assert out is None
 dist.barrier()
 dist.destroy_process_group()
 '''
 
 
-def test_gather_frame_gloo_world2(tmp_path):
-    """The N>1 path's only collective (framebuffer row gather), 2 processes over gloo on CPU."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_frame_gloo(tmp_path, world):
+    """The N>1 path's only collective (framebuffer row gather), 2 and 3 processes over gloo on CPU."""
     script = tmp_path / "w.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29517", str(script), ROOT], env=env, capture_output=True, text=True, timeout=240)
+    port = str(29517 + world)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", port, str(script), ROOT], env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "MERGE_OK" in r.stdout
