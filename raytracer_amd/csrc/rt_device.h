@@ -28,6 +28,7 @@
 #define RT_LEAF_COUNT(l)  (((l) >> 26) & 31u)
 #define RT_LEAF_MAX_FIRST 0x03FFFFF0u
 #define RT_LEAF_BIG       31u
+#define RT_NODE_RECORDS_MAX 0x01FFFFF0u   // node records a scene may have: their byte offsets (x 128) fit 32 bits (rt_traverse.h)
 
 // Two levels of a reference BVH (Bvh.h:39-49) collapsed into one 128-byte
 // record: for a reference interior node n with children L, R the four slots are

@@ -468,8 +468,10 @@ int build_mesh_level(rt_scene* sc, const rt_scene_desc* s) {
         rec_cap += s->mesh_bvhs[b].node_count / 2 + 1;
         if (!host_only && s->mesh_bvhs[b].node_count >= RT_COLLAPSE_MIN_NODES) max_dev_nodes = std::max(max_dev_nodes, s->mesh_bvhs[b].node_count);
     }
-    if (rec_cap >= 0x7FFFFFF0u - 2ull * s->n_top_nodes || s->n_mesh_prims >= RT_LEAF_MAX_FIRST)
-        return fail(RT_ERR_UNSUPPORTED, "scene too large for the link encoding (2^26 leaf prims)");
+    // (RT_NODE_RECORDS_MAX: the traversal addresses node records by 32-bit byte offsets, 128 B each — 4 GB of records;
+    // with at most 2^26 leaf prims a scene has about 2^25 of them, so the prim limit is the one that is met first)
+    if (rec_cap >= RT_NODE_RECORDS_MAX - 2ull * s->n_top_nodes || s->n_mesh_prims >= RT_LEAF_MAX_FIRST)
+        return fail(RT_ERR_UNSUPPORTED, "scene too large for the link encoding (2^26 leaf prims, 2^25 node records)");
     int rc;
     // the top level's records follow the meshes' in the same array: leave room for them (rt_update_scene grows it if needed)
     if ((rc = sc->b_nodes.ensure((rec_cap + std::max<size_t>(1024, 2 * (size_t)s->n_top_nodes)) * sizeof(DNode4)))) return rc;
@@ -667,8 +669,8 @@ int build_top_level(rt_scene* sc, const rt_scene_desc* s) {
         return fail(RT_ERR_UNSUPPORTED, "BVH too deep: a ray could need %u traversal stack entries (limit %d)", stack_need, RT_STACK_CAP_LIMIT);
     sc->stack_cap_derived = std::max<uint32_t>(RT_STACK_MIN_CAP, stack_need);
     sc->stack_cap = sc->stack_cap_override ? sc->stack_cap_override : sc->stack_cap_derived;
-    if ((uint64_t)M.n_node_records + nodes.size() >= 0x7FFFFFF0u || top.size() >= RT_LEAF_MAX_FIRST)
-        return fail(RT_ERR_UNSUPPORTED, "scene too large for the link encoding (2^26 leaf prims)");
+    if ((uint64_t)M.n_node_records + nodes.size() >= RT_NODE_RECORDS_MAX || top.size() >= RT_LEAF_MAX_FIRST)
+        return fail(RT_ERR_UNSUPPORTED, "scene too large for the link encoding (2^26 leaf prims, 2^25 node records)");
     std::sort(big.begin(), big.end(), [](const DBigLeaf& a, const DBigLeaf& b) { return a.first < b.first; });
     if (big.empty()) big.push_back(DBigLeaf{0, 0});
 

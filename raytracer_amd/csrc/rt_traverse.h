@@ -201,6 +201,12 @@ __device__ unsigned long long g_tl_tail[8];   // after the drain, summed over wa
 #define RT_TLC(v)
 #endif
 
+// Wave-wide votes of the hot loops, straight from the compare's lane mask (HIP's __ballot / __any go through an integer
+// per lane: a v_cndmask and a v_cmp more per vote).
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+__device__ __forceinline__ uint32_t wave_count(bool p) { return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); }
+
 typedef float f4a __attribute__((ext_vector_type(4)));
 typedef f4a f4u __attribute__((aligned(4)));   // 4 floats at dword alignment: one global_load_dwordx4
 
@@ -259,6 +265,16 @@ struct TraceStack {
                 e = spill[(sp - RT_STACK_LDS) * 64 + lane];
                 asm volatile("" : "+v"(e.x));   // keep the rare global path a branch (else both merge into one flat load)
             }
+            const float t = __uint_as_float(e.y);
+            if (e.x != RT_LINK_NONE && !((tmax < t) || (t == 0.0f && tmax <= 0.0f))) { t_out = t; return e.x; }
+        }
+        return RT_LINK_DONE;
+    }
+    // the same when the caller has established (wave-wide) that no lane's stack reaches into the global part
+    __device__ __forceinline__ uint32_t pop_lds(float tmax, float& t_out) {
+        while (sp > 0) {
+            --sp;
+            const uint2 e = lds[sp * 64 + lane];
             const float t = __uint_as_float(e.y);
             if (e.x != RT_LINK_NONE && !((tmax < t) || (t == 0.0f && tmax <= 0.0f))) { t_out = t; return e.x; }
         }
@@ -632,19 +648,22 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 // leaves: the walkers keep their place and go on in the next node phase.  (A wave completes a
                 // step about every 1.3 us whatever the number of active lanes, so steps with few lanes cost
                 // as much as full ones.)
-                const uint32_t n_want = (uint32_t)__popcll(__ballot(want)), n_wait = (uint32_t)__popcll(__ballot(!want && (qn != 0 || (RT_WAIT_COUNTS_TRANSITIONS && alive && !donated))));
+                const uint32_t n_want = wave_count(want), n_wait = wave_count(!want && (qn != 0 || (RT_WAIT_COUNTS_TRANSITIONS && alive && !donated)));
                 if (n_want == 0 || (n_want <= exit_few && n_wait >= exit_wait)) break;
                 // end game (subtrees are being donated): short node phases, so that posted subtrees are taken and
                 // new ones posted every few steps instead of once per ~30 — a long ray fans out over the idle lanes
                 if (split_now && ++phase_steps > (uint32_t)RT_TAIL_STEPS) break;
             }
+            // (wave-uniform, once per step: every stack entry touched in it — the pop after a queued leaf, up to three
+            // pushes, the pop of a lane that hit nothing — lies in the LDS part; the global part is the rare case)
+            const bool lds_only = !wave_any(want && st.sp + 3 > RT_STACK_LDS);
             if (want) {
                 if (leaf_here) {
                     RT_TL(tlr_leaves++;)
                     RT_STAT(st.acc->ray_leaves++;)
                     st.q[qn * 64 + st.lane] = make_uint2(cur, __float_as_uint(cur_t));
                     qn++;
-                    cur = st.pop(tmax, cur_t);
+                    cur = lds_only ? st.pop_lds(tmax, cur_t) : st.pop(tmax, cur_t);
                 }
                 if (!(cur & RT_LINK_LEAF)) {
                     RT_TL({ const unsigned long long b_ = __ballot(1); if ((int)lane == __ffsll((long long)b_) - 1) { tl_ns++; tl_nl += (uint32_t)__popcll(b_); } })
@@ -655,20 +674,22 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     // lane reads per axis the planes its ray meets first and the ones it meets last — min then max
                     // if 1/d >= 0 (+inf for d == 0 included), max then min otherwise — so the slab distances come
                     // out ordered without the reference's compare-and-swap (node_slabs4).
+                    // (32-bit byte offsets from the uniform base — the upload refuses node arrays of 4 GB — so that the seven
+                    // loads take the base from scalar registers and the lane's offset from one register each, instead of
+                    // seven 64-bit address sums)
                     const char* nodes_b = reinterpret_cast<const char*>(S.nodes);
-                    const uint64_t no = (uint64_t)cur << 7;
-                    const char* nb = nodes_b + no;
+                    const uint32_t no = cur << 7;
                     const uint32_t sx = (__float_as_uint(ar.ix) >> 31) << 4, sy = (__float_as_uint(ar.iy) >> 31) << 4,
                                    sz = (__float_as_uint(ar.iz) >> 31) << 4;
                     // (records are 128-byte aligned: the other 16-byte half of an axis' 32 bytes is the offset ^ 16)
-                    const uint64_t ox_ = no + sx, oy_ = no + sy, oz_ = no + sz;
+                    const uint32_t ox_ = no | sx, oy_ = no | sy, oz_ = no | sz;
                     const float4 nx = *reinterpret_cast<const float4*>(nodes_b + ox_), fx = *reinterpret_cast<const float4*>(nodes_b + (ox_ ^ 16u));
                     const float4 ny = *reinterpret_cast<const float4*>(nodes_b + oy_ + 32u), fy = *reinterpret_cast<const float4*>(nodes_b + (oy_ ^ 16u) + 32u);
                     const float4 nz = *reinterpret_cast<const float4*>(nodes_b + oz_ + 64u), fz = *reinterpret_cast<const float4*>(nodes_b + (oz_ ^ 16u) + 64u);
-                    const uint4 lk = *reinterpret_cast<const uint4*>(nb + 96u);
+                    const uint4 lk = *reinterpret_cast<const uint4*>(nodes_b + no + 96u);
                     float te4[4];
                     bool hit4[4];
-                    if (__builtin_expect(!__any(ray_is_odd(ar)), 1)) node_slabs4(ar, nx, fx, ny, fy, nz, fz, tmax, te4, hit4);
+                    if (__builtin_expect(!wave_any(ray_is_odd(ar)), 1)) node_slabs4(ar, nx, fx, ny, fy, nz, fz, tmax, te4, hit4);
                     else node_slabs4_any(ar, nx, fx, ny, fy, nz, fz, sx != 0u, sy != 0u, sz != 0u, tmax, te4, hit4);
                     const float t0 = te4[0], t1 = te4[1], t2 = te4[2], t3 = te4[3];
                     // slot 0 is always valid; an empty slot carries RT_LINK_DONE
@@ -694,7 +715,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
 #define RT_CSWAP(ka, la, kb, lb) { const bool s_ = ka > kb; const float kl_ = fminf(ka, kb), kh_ = fmaxf(ka, kb); const uint32_t ll_ = s_ ? lb : la, lh_ = s_ ? la : lb; ka = kl_; kb = kh_; la = ll_; lb = lh_; }
                         RT_CSWAP(k0, l0, k1, l1) RT_CSWAP(k2, l2, k3, l3) RT_CSWAP(k0, l0, k2, l2) RT_CSWAP(k1, l1, k3, l3) RT_CSWAP(k1, l1, k2, l2)
 #undef RT_CSWAP
-                        if (!__any(st.sp + 3 > RT_STACK_LDS)) {
+                        if (lds_only) {
                             if (k3 < INF) st.push_lds(l3, k3);
                             if (k2 < INF) st.push_lds(l2, k2);
                             if (k1 < INF) st.push_lds(l1, k1);
@@ -704,13 +725,13 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                             if (k1 < INF) st.push(l1, k1);
                         }
                         if (k0 < INF) { cur = l0; cur_t = k0; }
-                        else cur = st.pop(tmax, cur_t);
+                        else cur = lds_only ? st.pop_lds(tmax, cur_t) : st.pop(tmax, cur_t);
                         continue;
                     }
                     // visit order = slot order: the first hit slot is next, the later ones are
                     // pushed last-first so that they pop in order
                     const bool p1 = h1 & h0, p2 = h2 & (h0 | h1), p3 = h3 & (h0 | h1 | h2);
-                    if (!__any(st.sp + 3 > RT_STACK_LDS)) {
+                    if (lds_only) {
                         if (p3) st.push_lds(lk.w, t3);
                         if (p2) st.push_lds(lk.z, t2);
                         if (p1) st.push_lds(lk.y, t1);
@@ -723,7 +744,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     else if (h1) { cur = lk.y; cur_t = t1; }
                     else if (h2) { cur = lk.z; cur_t = t2; }
                     else if (h3) { cur = lk.w; cur_t = t3; }
-                    else cur = st.pop(tmax, cur_t);
+                    else cur = lds_only ? st.pop_lds(tmax, cur_t) : st.pop(tmax, cur_t);
                 }
             }
         }
@@ -802,8 +823,9 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 float tc[RT_TRI_UNROLL];
 #pragma unroll
                 for (uint32_t u = 0; u < RT_TRI_UNROLL; u++) {
-                    // 36-byte record as dwordx4 + dwordx4 + dword, all issued before the tests
-                    const float* tp = reinterpret_cast<const float*>(&S.tris[ti + (u < m ? u : 0u)]);
+                    // 36-byte record as dwordx4 + dwordx4 + dword, all issued before the tests (32-bit byte offset: a leaf's
+                    // first triangle is below RT_LEAF_MAX_FIRST, 36 x that is below 4 GB)
+                    const float* tp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(S.tris) + (ti + (u < m ? u : 0u)) * 36u);
                     ta[u] = *reinterpret_cast<const f4u*>(tp);
                     tb[u] = *reinterpret_cast<const f4u*>(tp + 4);
                     tc[u] = tp[8];
