@@ -247,6 +247,12 @@ struct TraceStack {
         lds[sp * 64 + lane] = make_uint2(link, __float_as_uint(t));
         sp++;
     }
+    // the same without a branch: the entry is written above the top in any case (free space: the caller has established
+    // that three more entries fit the LDS part) and the top only moves if `p` holds
+    __device__ __forceinline__ void push_lds_if(bool p, uint32_t link, float t) {
+        lds[sp * 64 + lane] = make_uint2(link, __float_as_uint(t));
+        sp += p ? 1u : 0u;
+    }
     __device__ __forceinline__ uint2 read_at(uint32_t pos) const {
         return pos < RT_STACK_LDS ? lds[pos * 64 + lane] : spill[(pos - RT_STACK_LDS) * 64 + lane];
     }
@@ -732,19 +738,18 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     // pushed last-first so that they pop in order
                     const bool p1 = h1 & h0, p2 = h2 & (h0 | h1), p3 = h3 & (h0 | h1 | h2);
                     if (lds_only) {
-                        if (p3) st.push_lds(lk.w, t3);
-                        if (p2) st.push_lds(lk.z, t2);
-                        if (p1) st.push_lds(lk.y, t1);
+                        st.push_lds_if(p3, lk.w, t3);
+                        st.push_lds_if(p2, lk.z, t2);
+                        st.push_lds_if(p1, lk.y, t1);
                     } else {
                         if (p3) st.push(lk.w, t3);
                         if (p2) st.push(lk.z, t2);
                         if (p1) st.push(lk.y, t1);
                     }
-                    if (h0) { cur = lk.x; cur_t = t0; }
-                    else if (h1) { cur = lk.y; cur_t = t1; }
-                    else if (h2) { cur = lk.z; cur_t = t2; }
-                    else if (h3) { cur = lk.w; cur_t = t3; }
-                    else cur = lds_only ? st.pop_lds(tmax, cur_t) : st.pop(tmax, cur_t);
+                    // (selects, then one branch for the lanes that hit nothing)
+                    cur = h0 ? lk.x : (h1 ? lk.y : (h2 ? lk.z : lk.w));
+                    cur_t = h0 ? t0 : (h1 ? t1 : (h2 ? t2 : t3));
+                    if (!(h0 | h1 | h2 | h3)) cur = lds_only ? st.pop_lds(tmax, cur_t) : st.pop(tmax, cur_t);
                 }
             }
         }
