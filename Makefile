@@ -28,7 +28,7 @@ $(PKG)/librt_hip_splittest.so: $(wildcard $(PKG)/csrc/*.hip $(PKG)/csrc/*.h) inc
 variant:
 	$(HIPCC) $(HIPFLAGS) $(DEFS) -I$(PKG)/csrc -o $(PKG)/librt_hip_$(NAME).so $(PKG)/csrc/rt_hip.hip
 
-oracle:
+oracle: hip host
 	$(MAKE) -C oracle all
 
 clean:
