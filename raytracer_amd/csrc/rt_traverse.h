@@ -124,6 +124,11 @@
 #ifndef RT_COOP_MIN
 #define RT_COOP_MIN 32           // a leaf with at least this many triangles can be tested by the whole wave for one ray
 #endif
+#ifndef RT_REFILL_PASSES
+#define RT_REFILL_PASSES 3       // refills per round: rays that end in their first transition (they miss every object box) leave lanes that
+                                 // are refilled at once, and the transition section stays a loop (with 1 the compiler made two copies of it):
+                                 // depth-first pixel loop +6 %, inst10 8K +1.6 %, the 1080p frames within the spread (profiles/r03/h_*)
+#endif
 #ifndef RT_CAND_MAX
 #define RT_CAND_MAX 16           // candidate hits a ray can collect from donated subtrees before it falls back to tracing alone
 #endif
@@ -1114,7 +1119,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             st.sp = 0;
         }
         if constexpr (MEGA) io.flush(lane, lanes_below);   // finished rays: hits to the shading wave, the others off the workgroup's count
-        if (tpass != 0 || (exhausted && !MEGA)) break;
+        if (tpass >= RT_REFILL_PASSES || (exhausted && !MEGA)) break;
         // ---- refill idle lanes
         bool refilled = false;
         if constexpr (MEGA) {
@@ -1210,8 +1215,8 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             // A wave that keeps a few idle lanes for RT_REFILL_PATIENCE rounds refills them anyway: they
             // would otherwise wait for the slowest rays, and the attempt is also how the wave learns that
             // the cursor is drained (from then on idle lanes help the busy ones, see subtree donation).
-            stale = n_idle != 0 ? stale + 1 : 0;
-            if (n_idle >= REFILL_MIN || stale > RT_REFILL_PATIENCE) {
+            if (tpass == 0) stale = n_idle != 0 ? stale + 1 : 0;
+            if (n_idle >= REFILL_MIN || (tpass == 0 && stale > RT_REFILL_PATIENCE)) {
                 stale = 0;
                 // the partition this workgroup draws from: its own (blockIdx % parts: workgroups that share an
                 // XCD, hence an L2, share a partition), then the others in turn
