@@ -285,11 +285,12 @@ int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out);
  * Frames equal the reference's wherever its box culls agree with its triangle tests; hit ids and
  * colours are tested to the north_star's tolerance, not to byte-exactness.  flags == 0 is rt_upload_scene.
  *
- * RT_UPLOAD_REBUILD_ON_DEVICE (with RT_UPLOAD_REBUILD_MESH_BVH): the rebuild runs on the GPU as a linear BVH (Morton
- * sort + Karras' radix tree, rt_lbvh.h) instead of the host's binned SAH: an upload of a 1 M-triangle scene in tens of
- * milliseconds instead of ~0.2 s, for trees that trace somewhat slower than the SAH ones.  Same
- * tolerance, same tie rule. */
-enum { RT_UPLOAD_REBUILD_MESH_BVH = 1u, RT_UPLOAD_REBUILD_ON_DEVICE = 2u };
+ * RT_UPLOAD_REBUILD_ON_DEVICE (with RT_UPLOAD_REBUILD_MESH_BVH): the rebuild runs on the GPU — the same binned SAH,
+ * decision for decision, level by level over the whole mesh and one wave per subtree of 64 triangles (rt_dsah.h): the
+ * host builder's trees in a few milliseconds of kernels instead of ~0.15 s of host threads per million triangles.
+ * RT_UPLOAD_REBUILD_LBVH (with both): a linear BVH instead (Morton sort + Karras' radix tree, rt_lbvh.h) — the
+ * cheapest build, for trees that trace 5-15 % slower than the SAH ones.  Same tolerance, same tie rule. */
+enum { RT_UPLOAD_REBUILD_MESH_BVH = 1u, RT_UPLOAD_REBUILD_ON_DEVICE = 2u, RT_UPLOAD_REBUILD_LBVH = 4u };
 int rt_upload_scene_ex(int device, const rt_scene_desc* scene, uint32_t flags, rt_scene** out);
 
 /* Next frame of an animation whose meshes do not change: re-derive everything

@@ -24,6 +24,7 @@
 #include "rt_upload.h"
 #include "rt_rebuild.h"
 #include "rt_lbvh.h"
+#include "rt_dsah.h"
 
 namespace {
 
@@ -758,11 +759,32 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s, uint32_t upload_fla
         rt_rebuild::MeshLevel R;
         if (upload_flags & RT_UPLOAD_REBUILD_ON_DEVICE) {
             const char* err = nullptr;
-            if (!rt_lbvh::rebuild(s, max_leaf, R, err)) return fail(RT_ERR_HIP, "LBVH rebuild: %s", err ? err : "?");
-            pc.lap("LBVH rebuild (device)");
+            if (upload_flags & RT_UPLOAD_REBUILD_LBVH) {
+                if (!rt_lbvh::rebuild(s, max_leaf, R, err)) return fail(RT_ERR_HIP, "LBVH rebuild: %s", err ? err : "?");
+                pc.lap("LBVH rebuild (device)");
+            } else {
+                if (!rt_dsah::rebuild(s, max_leaf, R, err)) return fail(RT_ERR_HIP, "SAH rebuild on the device: %s", err ? err : "?");
+                pc.lap("SAH rebuild (device)");
+            }
         } else {
             rt_rebuild::rebuild(s, max_leaf, R);
             pc.lap("SAH rebuild (host)");
+        }
+        if (getenv("RT_UPLOAD_TIMING")) {
+            // diagnostic: the SAH cost of every rebuilt tree (node areas + leaf areas x triangles, over the root's area), so
+            // that the builders can be compared without rendering — the device SAH builder must print the host builder's figures
+            for (uint32_t b = 0; b < s->n_mesh_bvhs; b++) {
+                const rt_bvh_node* nd = R.nodes.data() + R.bvhs[b].node_offset;
+                auto area = [](const rt_bvh_node& n) { const double dx = (double)n.bmax[0] - n.bmin[0], dy = (double)n.bmax[1] - n.bmin[1], dz = (double)n.bmax[2] - n.bmin[2]; return dx * dy + dy * dz + dz * dx; };
+                double cost = 0; uint64_t leaves = 0, tris = 0; uint32_t big = 0;
+                for (uint32_t i = 0; i < R.bvhs[b].node_count; i++) {
+                    if (nd[i].prim_count > 0) { cost += area(nd[i]) * nd[i].prim_count; leaves++; tris += (uint32_t)nd[i].prim_count; big = std::max(big, (uint32_t)nd[i].prim_count); }
+                    else cost += area(nd[i]);
+                }
+                const double ra = R.bvhs[b].node_count ? area(nd[0]) : 0.0;
+                fprintf(stderr, "[rt upload]   rebuilt BVH %u: %u nodes, %llu leaves (largest %u), %llu triangles, SAH cost %.6f\n", b, R.bvhs[b].node_count,
+                        (unsigned long long)leaves, big, (unsigned long long)tris, ra > 0 ? cost / ra : 0.0);
+            }
         }
         rt_scene_desc s2 = *s;
         s2.mesh_nodes = R.nodes.data(); s2.n_mesh_nodes = (uint32_t)R.nodes.size();
@@ -1354,8 +1376,9 @@ int rt_upload_scene(int device, const rt_scene_desc* scene, rt_scene** out) { re
 
 int rt_upload_scene_ex(int device, const rt_scene_desc* scene, uint32_t upload_flags, rt_scene** out) {
     if (!out) return fail(RT_ERR_INVALID, "out is NULL");
-    if (upload_flags & ~(uint32_t)(RT_UPLOAD_REBUILD_MESH_BVH | RT_UPLOAD_REBUILD_ON_DEVICE)) return fail(RT_ERR_INVALID, "unknown upload flag");
+    if (upload_flags & ~(uint32_t)(RT_UPLOAD_REBUILD_MESH_BVH | RT_UPLOAD_REBUILD_ON_DEVICE | RT_UPLOAD_REBUILD_LBVH)) return fail(RT_ERR_INVALID, "unknown upload flag");
     if ((upload_flags & RT_UPLOAD_REBUILD_ON_DEVICE) && !(upload_flags & RT_UPLOAD_REBUILD_MESH_BVH)) return fail(RT_ERR_INVALID, "RT_UPLOAD_REBUILD_ON_DEVICE goes with RT_UPLOAD_REBUILD_MESH_BVH");
+    if ((upload_flags & RT_UPLOAD_REBUILD_LBVH) && !(upload_flags & RT_UPLOAD_REBUILD_ON_DEVICE)) return fail(RT_ERR_INVALID, "RT_UPLOAD_REBUILD_LBVH goes with RT_UPLOAD_REBUILD_ON_DEVICE");
     *out = nullptr;
     // the description is checked first (host work only), so a malformed scene is reported as such on any box
     PhaseClock pc;

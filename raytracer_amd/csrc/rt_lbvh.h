@@ -243,7 +243,6 @@ inline bool rebuild(const rt_scene_desc* s, uint32_t max_leaf, rt_rebuild::MeshL
     RT_LBVH_CHK(d_sort.ensure(sort_bytes));
     lap("alloc + faces/vertices up");
 
-    std::vector<uint32_t> ref_pos;
     for (uint32_t b = 0; b < s->n_mesh_bvhs; b++) {
         rt_mesh_bvh& mb = out.bvhs[b];
         const size_t node_off = out.nodes.size();
@@ -309,11 +308,11 @@ inline bool rebuild(const rt_scene_desc* s, uint32_t max_leaf, rt_rebuild::MeshL
         RT_LBVH_CHK(hipGetLastError());
         out.nodes.resize(node_off + n_nodes);
         RT_LBVH_CHK(hipMemcpy(out.nodes.data() + node_off, d_out, (size_t)n_nodes * sizeof(rt_bvh_node), hipMemcpyDeviceToHost));
-        uint32_t* hpf = out.prim_face.data() + mb.prim_offset;
-        ref_pos.assign(mb.face_count, 0);
-        for (uint32_t p = 0; p < n; p++) ref_pos[hpf[p]] = p;
-        RT_LBVH_CHK(hipMemcpy(hpf, sf, (size_t)n * 4, hipMemcpyDeviceToHost));
-        for (uint32_t p = 0; p < n; p++) out.rank[mb.prim_offset + p] = mb.prim_offset + ref_pos[hpf[p]];
+        // leaf order of the new tree, and each slot's position in the caller's leaf order — which is what the sorted values are
+        RT_LBVH_CHK(hipMemcpy(out.prim_face.data() + mb.prim_offset, sf, (size_t)n * 4, hipMemcpyDeviceToHost));
+        uint32_t* rk = out.rank.data() + mb.prim_offset;
+        RT_LBVH_CHK(hipMemcpy(rk, val2, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (mb.prim_offset != 0) for (uint32_t p = 0; p < n; p++) rk[p] += mb.prim_offset;
         mb.node_offset = (uint32_t)node_off;
         mb.node_count = n_nodes;
         lap("download + rank");

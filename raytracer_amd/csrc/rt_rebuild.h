@@ -17,15 +17,30 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <thread>
+#include <utility>
 #include <vector>
 #include "rt.h"
 
 namespace rt_rebuild {
 
+// std::allocator whose value-less construct() default-initialises: resize() of a vector of PODs then does not write the
+// memory first (the device builders resize to a tree's node count and copy 35 MB per million triangles over it)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+    template <class U, class... A> void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+using NodeVec = std::vector<rt_bvh_node, NoInitAlloc<rt_bvh_node>>;
+
 struct MeshLevel {
-    std::vector<rt_bvh_node> nodes;        // all BVHs, concatenated
+    NodeVec nodes;                         // all BVHs, concatenated
     std::vector<rt_mesh_bvh> bvhs;         // node_offset / node_count rewritten, the rest as given
     std::vector<uint32_t> prim_face;       // leaf order of the rebuilt trees (same slots per BVH as the caller's array)
     std::vector<uint32_t> rank;            // per slot: position of that face in the caller's (the reference's) leaf order
@@ -196,7 +211,7 @@ struct Builder {
 // (node 0 of the BVH first) and reorders prim_face in place.  The upper levels are grown by this thread with
 // parallel binning; subtrees of a few thousand triangles are grown by all threads side by side and spliced in.
 inline void build_one(const rt_face* faces, const rt_vertex* vd, uint32_t* prim_face, uint32_t n, uint32_t max_leaf,
-                      std::vector<rt_bvh_node>& out) {
+                      NodeVec& out) {
     if (n == 0) return;
     const unsigned T = n >= 16384 ? host_threads() : 1;       // (small meshes: starting threads costs more than the build)
     uint32_t max_face = 0;

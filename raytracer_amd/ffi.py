@@ -18,6 +18,7 @@ RT_FLAG_PER_BOUNCE_LAUNCHES = 8
 RT_FLAG_ONE_LAUNCH = 16
 RT_UPLOAD_REBUILD_MESH_BVH = 1
 RT_UPLOAD_REBUILD_ON_DEVICE = 2
+RT_UPLOAD_REBUILD_LBVH = 4
 RT_UPDATE_VERIFY_MESHES = 1
 RT_OPT_FLAGS, RT_OPT_POOL_RECORDS, RT_OPT_CHUNK_SAMPLES, RT_OPT_STACK_CAP = 1, 2, 3, 4
 
@@ -366,11 +367,13 @@ class DeviceScene:
     def __init__(self, host_scene, device=0, rebuild_mesh_bvh=False):
         """rt_upload_scene; rebuild_mesh_bvh=True is rt_upload_scene_ex(RT_UPLOAD_REBUILD_MESH_BVH), the non-parity
         mode in which the library builds its own SAH trees over the meshes (include/rt.h); rebuild_mesh_bvh="device"
-        adds RT_UPLOAD_REBUILD_ON_DEVICE (a linear BVH built on the GPU)."""
+        adds RT_UPLOAD_REBUILD_ON_DEVICE (the same SAH trees built on the GPU), "lbvh" also RT_UPLOAD_REBUILD_LBVH (a
+        linear BVH built on the GPU)."""
         L = hip_lib()
         h = C.c_void_p()
         if rebuild_mesh_bvh:
-            flags = RT_UPLOAD_REBUILD_MESH_BVH | (RT_UPLOAD_REBUILD_ON_DEVICE if rebuild_mesh_bvh == "device" else 0)
+            flags = RT_UPLOAD_REBUILD_MESH_BVH | (RT_UPLOAD_REBUILD_ON_DEVICE if rebuild_mesh_bvh in ("device", "lbvh") else 0) \
+                | (RT_UPLOAD_REBUILD_LBVH if rebuild_mesh_bvh == "lbvh" else 0)
             _check(L.rt_upload_scene_ex(device, host_scene.desc_ptr, flags, C.byref(h)))
         else:
             _check(L.rt_upload_scene(device, host_scene.desc_ptr, C.byref(h)))

@@ -1,4 +1,5 @@
-"""Probe: mesh BVHs rebuilt on the device (LBVH) against the host SAH rebuild and the exact mode: upload time, render time, equality."""
+"""Probe: mesh BVHs rebuilt on the device (binned SAH: "device"; linear BVH: "lbvh") against the host SAH rebuild (True) and the caller's trees traced
+nearest-first (False): upload time, render time, equality.  RT_UPLOAD_TIMING=1 in the environment prints the phases and every tree's SAH cost."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,7 +10,7 @@ def run(tag, spec, reps=8):
     hs = spec.build()
     cam = hs.camera(0)
     ref = None
-    for mode in (False, True, "device"):
+    for mode in (False, True, "device", "lbvh"):
         ups = []
         ds = None
         for _ in range(3):

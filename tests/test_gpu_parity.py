@@ -687,23 +687,97 @@ def test_rebuilt_mesh_bvh_mode_vs_exact_mode_and_scene_update(rt):
 
 
 @pytest.mark.gpu
+def test_device_sah_builder_gives_the_host_builders_trees(rt):
+    """RT_UPLOAD_REBUILD_ON_DEVICE (rt_dsah.h) restates rt_rebuild.h's binned SAH decision for decision on quantities that do
+    not depend on the order of accumulation, so the trees are the host builder's: every frame and every hit id of a scene
+    uploaded either way must be EQUAL (ties between equal t go by the caller's leaf order in both).  Scenes: the bench
+    family, instances, the reference's scanned mesh and its many-mesh scene, meshes of 1 / 2 / 3 / 64 / 65 / 130 triangles
+    (the boundaries between 'one leaf', 'one wave' and 'level by level'), and coincident centroids (halved by position:
+    the host halves its own permutation, so there only the tolerance is asked for)."""
+    def frames(hs, mode):
+        ds = rt.DeviceScene(hs, 0, rebuild_mesh_bvh=mode)
+        cam = hs.camera(0)
+        rgb, hits = ds.render(cam, want_hits=True)
+        ds.close()
+        return rgb, hits
+    specs = [rt.scenes.mesh_scene(grid=200, width=640, height=360), rt.scenes.instanced_scene(grid=96, width=480, height=270),
+             rt.scenes.mesh_scene(grid=64, width=320, height=180, tessellation="cube")]
+    for spec in specs:
+        hs = spec.build()
+        a, b = frames(hs, True), frames(hs, "device")
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all(), (spec.name, int((a[0] != b[0]).any(-1).sum()))
+    for name in ("hw2_davids_camera_000", "hw2_two_berserkers", "hw1_cornellbox_recursive"):
+        hs = util.golden_scene(name)
+        a, b = frames(hs, True), frames(hs, "device")
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all(), (name, int((a[0] != b[0]).any(-1).sum()))
+    # small counts around the builder's regime boundaries: strips of n triangles side by side
+    for n in (1, 2, 3, 5, 63, 64, 65, 66, 129, 130, 257):
+        s = rt.scenes.SynthScene(f"strip_{n}")
+        s.max_depth = 0
+        s.ambient = (30, 30, 30)
+        verts, faces = [], []
+        for k in range(n):
+            x = -2.0 + 4.0 * k / max(n, 2)
+            w = 3.6 / max(n, 2)
+            verts += [(x, -1.0 + 0.3 * ((k * 7) % 5), -0.2 * (k % 3)), (x + w, -1.0, 0.1 * (k % 4)), (x + 0.5 * w, 1.0 - 0.2 * ((k * 3) % 4), 0.0)]
+            faces.append((3 * k, 3 * k + 1, 3 * k + 2))
+        s.materials = [dict(ambient=(1, 1, 1), diffuse=(0.7, 0.6, 0.5), specular=(0.2, 0.2, 0.2), phong=10.0)]
+        s.point_lights = [((0.5, 3.0, 5.0), (40000, 40000, 40000))]
+        s.meshes = [dict(verts=np.array(verts, np.float32), faces=np.array(faces, np.int32), material=1)]
+        s.camera = dict(position=(0.0, 0.2, 6.0), gaze_point=(0, 0, 0), up=(0, 1, 0), fovy=45.0, near=1.0, width=256, height=144, num_samples=1)
+        hs = s.build()
+        ex, a, b, c = frames(hs, False), frames(hs, True), frames(hs, "device"), frames(hs, "lbvh")
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all(), (n, int((a[0] != b[0]).any(-1).sum()))
+        for r in (b, c):
+            assert (r[1].reshape(-1, 2) == ex[1].reshape(-1, 2)).all(axis=1).mean() >= 0.9999 and (np.abs(r[0].astype(np.int16) - ex[0].astype(np.int16)).max(-1) <= 1).mean() >= 0.999, n
+    # coincident centroids: 300 triangles fanned around one centroid plus a normal strip (the reference leaves one big leaf)
+    s = rt.scenes.SynthScene("coincident")
+    s.max_depth = 0
+    s.ambient = (30, 30, 30)
+    verts, faces = [], []
+    for k in range(300):
+        ang = 2.0 * np.pi * k / 300.0
+        # three vertices at 120 degrees around the origin of the fan: every centroid is (0, 0, -0.001 k)
+        for j in range(3):
+            a_ = ang + 2.0 * np.pi * j / 3.0
+            verts.append((1.5 * np.cos(a_), 1.5 * np.sin(a_), -0.003 * k))
+        faces.append((3 * k, 3 * k + 1, 3 * k + 2))
+    base = len(verts)
+    for k in range(80):
+        x = -3.0 + 0.07 * k
+        verts += [(x, -2.0, 0.5), (x + 0.06, -2.0, 0.5), (x + 0.03, -1.6, 0.5)]
+        faces.append((base + 3 * k, base + 3 * k + 1, base + 3 * k + 2))
+    s.materials = [dict(ambient=(1, 1, 1), diffuse=(0.7, 0.6, 0.5), specular=(0.2, 0.2, 0.2), phong=10.0)]
+    s.point_lights = [((0.5, 3.0, 5.0), (40000, 40000, 40000))]
+    s.meshes = [dict(verts=np.array(verts, np.float32), faces=np.array(faces, np.int32), material=1)]
+    s.camera = dict(position=(0.0, 0.0, 6.0), gaze_point=(0, 0, 0), up=(0, 1, 0), fovy=45.0, near=1.0, width=256, height=144, num_samples=1)
+    hs = s.build()
+    ex = frames(hs, False)
+    for mode in (True, "device", "lbvh"):
+        r = frames(hs, mode)
+        same = (r[1].reshape(-1, 2) == ex[1].reshape(-1, 2)).all(axis=1).mean()
+        close = (np.abs(r[0].astype(np.int16) - ex[0].astype(np.int16)).max(-1) <= 1).mean()
+        assert same >= 0.9999 and close >= 0.999, (mode, same, close)
+
+
+@pytest.mark.gpu
 def test_mesh_bvhs_rebuilt_on_the_device_meet_the_tolerance(rt):
-    """RT_UPLOAD_REBUILD_MESH_BVH | RT_UPLOAD_REBUILD_ON_DEVICE (SURVEY 8f-3 on the GPU, rt_lbvh.h): linear BVHs built by
-    Morton sort + Karras' radix tree, emitted in the reference's node format.  Same bar as the host rebuild: the
+    """RT_UPLOAD_REBUILD_MESH_BVH | RT_UPLOAD_REBUILD_ON_DEVICE (SURVEY 8f-3 on the GPU): the binned SAH of rt_dsah.h and, with
+    RT_UPLOAD_REBUILD_LBVH, linear BVHs built by Morton sort + Karras' radix tree (rt_lbvh.h), both emitted in the reference's node format.  Same bar as the host rebuild: the
     north_star's tolerance against the reference's own renders on mesh scenes of every kind (many overlapping meshes, a
     scanned 100 000-face mesh, instances under a one-leaf top level, inline meshes, a binary PLY with a rough material),
     and against the exact mode on the bench's scene family; rt_update_scene keeps the device-built trees."""
-    for name in ("hw1_cornellbox_recursive", "hw2_two_berserkers", "hw2_davids_camera_000", "hw2_grass_desert", "hw2_metal_glass_plates",
-                 "hw3_chessboard_arealight", "hw3_tap_0100"):
+    for name, mode in [(n_, m_) for m_ in ("device", "lbvh") for n_ in ("hw1_cornellbox_recursive", "hw2_two_berserkers", "hw2_davids_camera_000", "hw2_grass_desert",
+                                                                      "hw2_metal_glass_plates", "hw3_chessboard_arealight", "hw3_tap_0100")]:
         hs = util.golden_scene(name)
         cam = hs.camera(0)
-        ds = rt.DeviceScene(hs, 0, rebuild_mesh_bvh="device")
+        ds = rt.DeviceScene(hs, 0, rebuild_mesh_bvh=mode)
         tile = util.golden_tile(name) or (0, 0, cam.image_width, cam.image_height)
         rgb, hits = ds.render(cam, *tile, want_hits=True)
         ds.close()
         st = util.image_stats(rgb, util.golden_image(name))
         ok = util.hit_ids_match(hits, util.golden_hits(name), hs)
-        print(f"device-rebuilt {name}: hit ids {ok.mean():.6f} exact {st['exact']:.6f} within1 {st['within1']:.6f}")
+        print(f"device-rebuilt ({mode}) {name}: hit ids {ok.mean():.6f} exact {st['exact']:.6f} within1 {st['within1']:.6f}")
         assert ok.mean() >= 0.9999, (name, ok.mean())
         assert st["within1"] >= 0.999, (name, st)
     for spec in (rt.scenes.mesh_scene(grid=256, width=960, height=540), rt.scenes.instanced_scene(grid=128, width=640, height=360),
@@ -714,7 +788,7 @@ def test_mesh_bvhs_rebuilt_on_the_device_meet_the_tolerance(rt):
         s0, s1 = rt.Stats(), rt.Stats()
         rgb0, hits0 = ds.render(cam, want_hits=True, stats=s0)
         ds.close()
-        ds = rt.DeviceScene(hs, 0, rebuild_mesh_bvh="device")
+        ds = rt.DeviceScene(hs, 0, rebuild_mesh_bvh="lbvh" if spec.name.startswith("inst") else "device")
         rgb1, hits1 = ds.render(cam, want_hits=True, stats=s1)
         ds.update(hs, verify_meshes=True)
         rgb2, hits2 = ds.render(cam, want_hits=True)
