@@ -368,9 +368,13 @@ def main():
                 line["rebuilt_bvh"]["upload_seconds"] = r3.upload_seconds
                 r3.close()
                 r4 = Run(e, spec, rebuild="device", hs=run.hs)
-                line["rebuilt_bvh_on_device"] = extra_leg(r4, "non-parity mode: linear BVHs built on the GPU (Morton sort + radix tree, rt_lbvh.h), traced nearest first; opt-in (rt_upload_scene_ex)")
+                line["rebuilt_bvh_on_device"] = extra_leg(r4, "non-parity mode: the same binned-SAH trees built on the GPU (rt_dsah.h), traced nearest first; opt-in (rt_upload_scene_ex)")
                 line["rebuilt_bvh_on_device"]["upload_seconds"] = r4.upload_seconds
                 r4.close()
+                r5 = Run(e, spec, rebuild="lbvh", hs=run.hs)
+                line["rebuilt_lbvh_on_device"] = extra_leg(r5, "non-parity mode: linear BVHs built on the GPU (Morton sort + radix tree, rt_lbvh.h), traced nearest first; opt-in (rt_upload_scene_ex)")
+                line["rebuilt_lbvh_on_device"]["upload_seconds"] = r5.upload_seconds
+                r5.close()
             # the workload of the N > 1 runs on this one GPU: the base of the strong-scaling curve
             rs = Run(e, scenes.instanced_scene(args.grid, strong_w, strong_h))
             k = max(2, min(5, args.steps))

@@ -7,7 +7,7 @@ r = d["roofline"]
 print("roofline", {k: r.get(k) for k in ("kernel", "frac", "avg_launch_ms", "traffic", "saturated")})
 print("binding", r.get("binding"))
 print("other", r.get("other_kernel"))
-for k in ("near_first", "rebuilt_bvh", "rebuilt_bvh_on_device"):
+for k in ("near_first", "rebuilt_bvh", "rebuilt_bvh_on_device", "rebuilt_lbvh_on_device"):
     if k in d:
         print(k, round(d[k]["value"], 1), round(d[k]["closest_ms_per_step"], 4), d[k]["pixels_equal_to_exact_frame"])
 for k in ("strong_scaling_base", "strong_scaling_projection", "cpu_baseline", "parity_vs_cpu_reference"):
