@@ -182,7 +182,7 @@ struct Gpu {
 
 struct Options {
     int gpus = 1, bench = 0, tile_w = 0, tile_h = 0;
-    bool near_first = false, rebuild_bvh = false, rebuild_on_device = false, serial = false;
+    bool near_first = false, rebuild_bvh = false, rebuild_on_device = false, rebuild_lbvh = false, serial = false;
     std::string backend = "hip", dump_hits;
 };
 
@@ -281,7 +281,7 @@ static const char* place_scene(std::vector<Gpu>& gpus, const RtSceneStore& flat,
         if (rc != RT_OK) {                       // other meshes than the resident ones (or the first frame): a fresh upload
             how = "upload";
             if (G.scene) { rt_free_scene(G.scene); G.scene = nullptr; }
-            rc = rt_upload_scene_ex(G.device, &flat.desc, opt.rebuild_bvh ? (RT_UPLOAD_REBUILD_MESH_BVH | (opt.rebuild_on_device ? RT_UPLOAD_REBUILD_ON_DEVICE : 0u)) : 0u, &G.scene);
+            rc = rt_upload_scene_ex(G.device, &flat.desc, opt.rebuild_bvh ? (RT_UPLOAD_REBUILD_MESH_BVH | (opt.rebuild_on_device ? RT_UPLOAD_REBUILD_ON_DEVICE : 0u) | (opt.rebuild_lbvh ? RT_UPLOAD_REBUILD_LBVH : 0u)) : 0u, &G.scene);
             if (rc == RT_OK && opt.near_first) rc = rt_scene_set_option(G.scene, RT_OPT_FLAGS, RT_FLAG_NEAR_FIRST);
             if (rc != RT_OK) { G.err = rt_last_error(); return ""; }
         }
@@ -293,7 +293,7 @@ static const char* place_scene(std::vector<Gpu>& gpus, const RtSceneStore& flat,
 int main(int argc, char* argv[]) {
     if (argc < 2) {
         printf("Usage: %s <scene.json> [more.json ...] [--frames PREFIX START END] [--gpus N] [--backend hip|cpu] [--tile WxH] [--bench K] "
-               "[--serial] [--dump-hits file] [--near-first] [--rebuild-bvh[=device]]\n", argv[0]);
+               "[--serial] [--dump-hits file] [--near-first] [--rebuild-bvh[=device|=lbvh]]\n", argv[0]);
         return -1;
     }
     Options opt;
@@ -304,7 +304,8 @@ int main(int argc, char* argv[]) {
         else if (!strcmp(argv[i], "--dump-hits") && i + 1 < argc) opt.dump_hits = argv[++i];
         else if (!strcmp(argv[i], "--near-first")) opt.near_first = true;
         else if (!strcmp(argv[i], "--rebuild-bvh")) opt.rebuild_bvh = true;
-        else if (!strcmp(argv[i], "--rebuild-bvh=device")) opt.rebuild_bvh = opt.rebuild_on_device = true;   // rt_lbvh.h: built on the GPU
+        else if (!strcmp(argv[i], "--rebuild-bvh=device")) opt.rebuild_bvh = opt.rebuild_on_device = true;   // rt_dsah.h: the same SAH trees built on the GPU
+        else if (!strcmp(argv[i], "--rebuild-bvh=lbvh")) opt.rebuild_bvh = opt.rebuild_on_device = opt.rebuild_lbvh = true;   // rt_lbvh.h: linear BVHs built on the GPU
         else if (!strcmp(argv[i], "--serial")) opt.serial = true;
         else if (!strcmp(argv[i], "--bench") && i + 1 < argc) opt.bench = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--tile") && i + 1 < argc) {
