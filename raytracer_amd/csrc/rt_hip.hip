@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <string>
 #include <chrono>
 #include <mutex>
@@ -453,10 +454,23 @@ struct PhaseClock {
 };
 
 // The mesh level: collapsed mesh BVHs, leaf-ordered triangle records, shading data, vertex normals.
-int build_mesh_level(rt_scene* sc, const rt_scene_desc* s) {
+// (hash_of: the description whose mesh arrays rt_update_scene will be compared with — the caller's, also when the trees
+// were rebuilt.  The hash and the two host walks over the node arrays run on threads of their own beside the device work.)
+int build_mesh_level(rt_scene* sc, const rt_scene_desc* s, const rt_scene_desc* hash_of) {
     PhaseClock pc;
     std::vector<DNode4> nodes;
     std::vector<DBigLeaf> big;
+    std::future<uint64_t> fut_hash = std::async(std::launch::async, [hash_of] { return mesh_hash(hash_of); });
+    struct Walk { bool ascending; uint32_t stack_need; };
+    std::future<Walk> fut_walk = std::async(std::launch::async, [s] {
+        Walk w{true, 0u};
+        for (uint32_t b = 0; b < s->n_mesh_bvhs; b++) {
+            const rt_bvh_node* nd = s->mesh_nodes + s->mesh_bvhs[b].node_offset;
+            if (!leaves_ascending(nd, s->mesh_bvhs[b].node_count)) w.ascending = false;
+            w.stack_need = std::max(w.stack_need, stack_need_of_depth(bvh_depth(nd, s->mesh_bvhs[b].node_count)));
+        }
+        return w;
+    });
 
     // mesh BVHs -> node records.  Large BVHs are collapsed on the device (rt_upload.h), small ones on the host;
     // the records of BVH b follow those of BVH b - 1 in the node array either way.
@@ -553,12 +567,6 @@ int build_mesh_level(rt_scene* sc, const rt_scene_desc* s) {
     }
     if ((rc = flush_host_records())) return rc;
     pc.lap("mesh BVH collapse");
-    sc->mesh_stack_need = 0;
-    for (uint32_t b = 0; b < s->n_mesh_bvhs; b++) {
-        if (!leaves_ascending(s->mesh_nodes + s->mesh_bvhs[b].node_offset, s->mesh_bvhs[b].node_count)) donate_ok = false;
-        sc->mesh_stack_need = std::max(sc->mesh_stack_need, stack_need_of_depth(bvh_depth(s->mesh_nodes + s->mesh_bvhs[b].node_offset, s->mesh_bvhs[b].node_count)));
-    }
-    pc.lap("leaf order + depth (host)");
     // triangle records, shading records and vertex normals: gathered on the device from the caller's arrays
     if ((rc = sc->b_tris.ensure(std::max<size_t>(s->n_mesh_prims, 1) * sizeof(DTri))) ||
         (rc = sc->b_tri_shade.ensure(std::max<size_t>(s->n_mesh_prims, 1) * sizeof(DTriShade))) ||
@@ -599,8 +607,13 @@ int build_mesh_level(rt_scene* sc, const rt_scene_desc* s) {
     M.n_node_records = rec_count;
     M.n_mesh_bvhs = s->n_mesh_bvhs; M.n_mesh_nodes = s->n_mesh_nodes; M.n_mesh_prims = s->n_mesh_prims;
     M.n_faces = s->n_faces; M.n_vertices = s->n_vertices;
-    M.hash = mesh_hash(s);
-    pc.lap("mesh hash");
+    {
+        const Walk w = fut_walk.get();
+        if (!w.ascending) donate_ok = false;
+        sc->mesh_stack_need = w.stack_need;
+    }
+    M.hash = fut_hash.get();
+    pc.lap("leaf order + depth, mesh hash (host threads, waited for)");
     M.donate_ok = donate_ok;
     sc->ds.tris = (const DTri*)sc->b_tris.p;
     sc->ds.tri_shade = (const DTriShade*)sc->b_tri_shade.p;
@@ -792,15 +805,14 @@ int build_device_scene(rt_scene* sc, const rt_scene_desc* s, uint32_t upload_fla
         s2.mesh_prim_face = R.prim_face.data();
         for (uint32_t b = 0; b < s2.n_mesh_bvhs; b++)
             if ((rc = validate_bvh(s2.mesh_nodes + s2.mesh_bvhs[b].node_offset, s2.mesh_bvhs[b].node_count, s2.mesh_bvhs[b].prim_count, "rebuilt mesh BVH"))) return rc;
-        if ((rc = build_mesh_level(sc, &s2))) return rc;
-        // rt_update_scene compares the caller's arrays with what the caller uploaded
+        if ((rc = build_mesh_level(sc, &s2, s))) return rc;
+        // rt_update_scene compares the caller's arrays with what the caller uploaded (the hash is of `s` already)
         sc->mesh.n_mesh_nodes = s->n_mesh_nodes;
-        sc->mesh.hash = mesh_hash(s);
         if ((rc = upload_vec(sc->b_tri_rank, R.rank))) return rc;
         sc->ds.tri_rank = R.rank.empty() ? nullptr : (const uint32_t*)sc->b_tri_rank.p;
         sc->rebuilt = true;
     } else {
-        if ((rc = build_mesh_level(sc, s))) return rc;
+        if ((rc = build_mesh_level(sc, s, s))) return rc;
         sc->ds.tri_rank = nullptr;
     }
     return build_top_level(sc, s);
