@@ -93,6 +93,9 @@ def cpu_baseline(scene_spec, gpu_rgb):
     return out, parity
 
 
+STATS_EVERY = 4      # Run.timed: one step in four is rendered with per-kernel HIP-event times (rt_stats)
+
+
 class Run:
     """One scene resident on this rank's GPU + its share of one frame; timed() runs W + K steps."""
 
@@ -107,12 +110,17 @@ class Run:
         t = time.perf_counter()
         self.ds = DeviceScene(self.hs, env.local_rank, rebuild_mesh_bvh=rebuild)
         self.upload_seconds = time.perf_counter() - t
+        self.flags = flags
+        self.timing = True
         self.ds.set_option(RT_OPT_FLAGS, RT_FLAG_TIMING | flags)
         self.fb = torch.zeros((self.H, self.W, 3), dtype=torch.uint8, device=env.dev)
 
     def step(self, st=None):
-        from raytracer_amd import multigpu
+        from raytracer_amd import multigpu, RT_OPT_FLAGS, RT_FLAG_TIMING
         e = self.env
+        if (st is not None) != self.timing:                  # event brackets (and the wait for them) only where rt_stats is asked for
+            self.timing = st is not None
+            self.ds.set_option(RT_OPT_FLAGS, (RT_FLAG_TIMING if self.timing else 0) | self.flags)
         self.ds.render_rows_device(self.cam, 0, 0, self.W, self.H, e.world, e.rank, self.fb.data_ptr(), self.W * 3, stats=st, stream=e.stream)
         return multigpu.gather_frame(self.fb, e.rank, e.world, force=e.dist)
 
@@ -129,9 +137,17 @@ class Run:
         e.fence()
         t0 = time.perf_counter()
         frame = None
-        for _ in range(steps):
-            st = Stats()
+        # Every STATS_EVERY-th step asks for rt_stats — its kernels are then bracketed by HIP events on the render's stream and
+        # the call returns when they are done, which is where the roofline's launch times come from, live, inside the timed
+        # region — the others are queued behind each other as a frame loop would queue them (a depth-0 render without
+        # rt_stats returns before its kernels have run; include/rt.h).  The sampled times are scaled to all steps.
+        sampled = 0
+        for i in range(steps):
+            st = Stats() if i % STATS_EVERY == 0 else None
             frame = self.step(st)
+            if st is None:
+                continue
+            sampled += 1
             for k in ("raygen", "closest", "shade", "shadow", "combine", "resolve"):
                 acc[k] += getattr(st, "ms_" + k)
             acc["n_closest"] += st.launches_closest
@@ -139,6 +155,9 @@ class Run:
             rays = [st.rays_primary, st.rays_secondary, st.rays_shadow]
         e.fence()
         elapsed = time.perf_counter() - t0
+        self.ds.sync()                                        # (reports what an asynchronous step left behind, if anything)
+        for k in acc:
+            acc[k] *= steps / max(sampled, 1)
         t = torch.tensor([elapsed], dtype=torch.float64, device=e.dev)
         r = torch.tensor(rays, dtype=torch.float64, device=e.dev)
         if e.dist:
