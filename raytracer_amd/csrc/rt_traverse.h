@@ -124,6 +124,12 @@
 #ifndef RT_COOP_MIN
 #define RT_COOP_MIN 32           // a leaf with at least this many triangles can be tested by the whole wave for one ray
 #endif
+#ifndef RT_MIXED_PARTS
+#define RT_MIXED_PARTS 1         // the mixed launches' cursor is partitioned like the others' (0: one cursor)
+#endif
+#ifndef RT_STATIC_FIRST
+#define RT_STATIC_FIRST 1        // the first batch of every wave is its own by position, no atomic (0: everything through the cursors)
+#endif
 #ifndef RT_REFILL_PASSES
 #define RT_REFILL_PASSES 3       // refills per round: rays that end in their first transition (they miss every object box) leave lanes that
                                  // are refilled at once, and the transition section stays a loop (with 1 the compiler made two copies of it):
@@ -432,9 +438,20 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
     // A large generation is cut into RT_PARTS contiguous partitions, each with a cursor of its own, and a
     // workgroup starts on partition blockIdx % RT_PARTS: the workgroups that share an XCD work on one part of
     // the image (of the record pool), so that XCD's L2 holds that part's share of the BVH instead of all of it.
-    const uint32_t parts = (LINGER && (!MIXED || MEGA) && n_blocks >= RT_PARTS_MIN_BLOCKS) ? (uint32_t)RT_PARTS : 1u;
+    // (mixed launches too: a partition holds its share of the closest-hit blocks, handed out first, and its share of the any-hit
+    // blocks — with one cursor for all 4096 waves the refills themselves queued on that word)
+    const uint32_t parts = (LINGER && (RT_MIXED_PARTS || !MIXED || MEGA) && n_blocks >= RT_PARTS_MIN_BLOCKS) ? (uint32_t)RT_PARTS : 1u;
     const uint32_t part0 = LINGER ? blockIdx.x % parts : 0u;
     uint32_t parts_done = 0;     // wave-uniform: partitions this wave knows to be drained
+    // The first 64 items of every wave are its own by position — wave k of a partition's workgroups takes cursor values
+    // [64 k, 64 k + 64) of that partition — and the cursors hand out what lies behind those: when a launch starts, every
+    // wave of the chip would otherwise add to the same few words at once, and same-address atomics queue at ~60 ns each
+    // (512 waves per cursor: the last one starts 30 us late; 4096 on the mixed launches' one cursor: 245 us).
+    bool first_fill = RT_STATIC_FIRST && LINGER && !MEGA;   // wave-uniform: that batch is still to be taken
+    const uint32_t waves_per_wg = blockDim.x >> 6;
+    auto static_items = [&](uint32_t part) -> uint32_t {     // cursor values of partition `part` that are taken by position
+        return (RT_STATIC_FIRST && LINGER && !MEGA) ? ((gridDim.x + parts - 1u - part) / parts) * waves_per_wg * 64u : 0u;
+    };
     uint32_t stale = 0;          // wave-uniform: rounds with idle lanes since the last refill
     uint32_t idle_rounds = 0;    // MEGA, wave-uniform: consecutive rounds without a ray in this wave (bounded)
     // MEGA: a wave that takes shadow slots first runs with the any-hit kernel's phase thresholds, and an any-hit lane
@@ -466,7 +483,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             }
             tl_ns = tl_nl = tl_ts = tl_tlanes = 0;
         })
-        if (LINGER && !exhausted) {                  // partitions other waves of the workgroup have seen drained
+        if (LINGER && !exhausted && !first_fill) {   // partitions other waves of the workgroup have seen drained
             const uint32_t d = st.blk[4];
             if (d > parts_done) {
                 parts_done = d;
@@ -1221,11 +1238,26 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 // the partition this workgroup draws from: its own (blockIdx % parts: workgroups that share an
                 // XCD, hence an L2, share a partition), then the others in turn
                 const uint32_t part = (part0 + parts_done) % parts;
-                const uint32_t pb0 = (uint32_t)((uint64_t)n_blocks * part / parts);
-                const uint32_t pnb = (uint32_t)((uint64_t)n_blocks * (part + 1u) / parts) - pb0, p_padded = pnb * 64u;
+                uint32_t pb0, pnb, pa0 = 0, pc_n = 0;         // this partition's blocks; MIXED: pb0 / pc_n closest-hit blocks, pa0 first any-hit block
+                if constexpr (MIXED) {
+                    const uint32_t nb1 = io.first_blocks(), nba = n_blocks - nb1;
+                    pb0 = (uint32_t)((uint64_t)nb1 * part / parts);
+                    pc_n = (uint32_t)((uint64_t)nb1 * (part + 1u) / parts) - pb0;
+                    pa0 = (uint32_t)((uint64_t)nba * part / parts);
+                    pnb = pc_n + ((uint32_t)((uint64_t)nba * (part + 1u) / parts) - pa0);
+                } else {
+                    pb0 = (uint32_t)((uint64_t)n_blocks * part / parts);
+                    pnb = (uint32_t)((uint64_t)n_blocks * (part + 1u) / parts) - pb0;
+                }
+                const uint32_t p_padded = pnb * 64u;
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(cursor + part * RT_CURSOR_STRIDE, n_idle);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (first_fill) {                            // (all 64 lanes are idle: nothing has been loaded yet)
+                    base = ((blockIdx.x / parts) * waves_per_wg + (st.slot >> 6)) * 64u;
+                    first_fill = false;
+                } else {
+                    if (lane == 0) base = atomicAdd(cursor + part * RT_CURSOR_STRIDE, n_idle);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + static_items(part);
+                }
                 if (base + n_idle >= p_padded) {
                     parts_done++;
                     if (LINGER && lane == 0) atomicMax(&st.blk[4], parts_done);
@@ -1243,13 +1275,12 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                             // first the closest-hit items, strip-interleaved over their blocks; then the any-hit
                             // items block by block (item ids: the first kind's padded count, then the second kind) —
                             // the cheap any-hit rays are what is in flight when the cursor runs dry
-                            const uint32_t nb1 = io.first_blocks();
-                            if (c < nb1 * 64u) {
+                            if (c < pc_n * 64u) {
                                 const uint32_t strip = c / STRIP, within = c % STRIP;
-                                i = (strip % nb1) * 64u + (strip / nb1) * STRIP + within;
+                                i = (pb0 + strip % pc_n) * 64u + (strip / pc_n) * STRIP + within;
                                 valid = i < io.first_count();
                             } else {
-                                i = c;
+                                i = (io.first_blocks() + pa0) * 64u + (c - pc_n * 64u);
                                 valid = i < end;
                             }
                             i += begin;
