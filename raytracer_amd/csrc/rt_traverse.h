@@ -124,6 +124,9 @@
 #ifndef RT_COOP_MIN
 #define RT_COOP_MIN 32           // a leaf with at least this many triangles can be tested by the whole wave for one ray
 #endif
+#ifndef RT_EARLY_FINISH
+#define RT_EARLY_FINISH 1        // a ray whose stack runs empty in the transition pass is retired in that pass
+#endif
 #ifndef RT_MIXED_PARTS
 #define RT_MIXED_PARTS 1         // the mixed launches' cursor is partitioned like the others' (0: one cursor)
 #endif
@@ -1105,7 +1108,12 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 }
             }
             if (fin) { finished = true; break; }
-            if (!entered) cur = st.pop(tmax, cur_t);
+            if (!entered) {
+                cur = st.pop(tmax, cur_t);
+                // An empty stack is the end of the ray: seen here, not in the next round's pass (the ray kept its lane
+                // for a round of its wave with nothing to do in it)
+                if (RT_EARLY_FINISH && cur == RT_LINK_DONE) finished = true;
+            }
         } while (0);
 
         if (alive && finished) {
