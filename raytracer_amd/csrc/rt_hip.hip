@@ -1324,9 +1324,16 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
                 (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rayhist), rh, sizeof(rh));
             }
         }
-        fprintf(stderr, "[rt stats] board: donor-eligible lane-rounds %llu, gated by idle<=ready %llu, slot busy %llu, claims %llu\n", d[6], d[7], d[8], d[9]);
-        fprintf(stderr, "[rt stats] closest timing: waves=%llu kernel span %.1f us, wave lifetime mean %.1f min %.1f max %.1f us\n",
-                d[13], (d[11] - ~d[10]) * 0.01, d[13] ? d[12] * 0.01 / d[13] : 0.0, (~d[15]) * 0.01, d[14] * 0.01);
+        fprintf(stderr, "[rt stats] transitions, summed over waves: %.0f us = block %.0f + retire %.0f + refill %.0f us in %llu passes\n",
+                d[10] * 0.01, d[6] * 0.01, d[7] * 0.01, d[8] * 0.01, d[9]);
+        {
+            unsigned long long y[8] = {0}, z[8] = {0};
+            if (hipMemcpyFromSymbol(y, HIP_SYMBOL(g_ydbg), sizeof(y)) == hipSuccess) {
+                fprintf(stderr, "[rt stats] transition block: mesh end %.0f us, prims loop %.0f us; bodies run %llu (lanes %llu), prim iterations %llu (lanes %llu)\n",
+                        y[0] * 0.01, y[1] * 0.01, y[4], y[5], y[2], y[3]);
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ydbg), z, sizeof(z));
+            }
+        }
     }
 #endif
     if (stats) {

@@ -203,6 +203,39 @@ __device__ __forceinline__ TraceStack make_stack(TraceLds<THREADS>& L, uint2* sp
 
 #ifdef RT_TRACE_STATS
 __device__ unsigned long long g_wave_dbg[8192][16];   // per wave of k_trace_closest (diagnostic build)
+__device__ unsigned long long g_ydbg[8];                // inside the transition block, summed over waves
+
+// diagnostic build: totals into ctl->dbg, per-wave breakdown into g_wave_dbg (printed by render_impl)
+__device__ void report_trace_stats(Control* ctl, const TraceStatsAcc& acc, unsigned long long traced, unsigned long long clk_start,
+                                   const TraceStack& st, const WaveWork& ww) {
+    atomicAdd(&ctl->dbg[0], acc.wave_node_steps); atomicAdd(&ctl->dbg[1], acc.lane_node_steps);
+    atomicAdd(&ctl->dbg[2], acc.wave_tri_steps); atomicAdd(&ctl->dbg[3], acc.lane_tri_steps);
+    atomicAdd(&ctl->dbg[4], acc.wave_outer);
+    const uint32_t wg = blockIdx.x * (blockDim.x / 64) + ww.wave;
+    if (ww.lane == 0) {
+        atomicAdd(&ctl->dbg[5], traced);
+        const unsigned long long clk_end = wall_clock64();
+        if (wg < 8192) {
+            unsigned long long* o = g_wave_dbg[wg];
+            o[0] = clk_end - clk_start; o[1] = acc.clk_exhausted ? acc.clk_exhausted - clk_start : 0; o[2] = acc.t_sched; o[3] = acc.t_node;
+            o[4] = acc.t_tri; o[5] = acc.t_big; o[6] = acc.t_trans; o[7] = 0; o[8] = 0; o[9] = 0;
+            atomicAdd(&ctl->dbg[6], acc.x_block); atomicAdd(&ctl->dbg[7], acc.x_retire); atomicAdd(&ctl->dbg[8], acc.x_refill); atomicAdd(&ctl->dbg[9], acc.x_passes); atomicAdd(&ctl->dbg[10], acc.t_trans); atomicAdd(&ctl->dbg[11], acc.wave_outer ? 0ull : 0ull);
+            o[10] = acc.n_donations; o[11] = acc.n_coop; o[12] = traced; o[13] = 0; o[14] = 0; o[15] = clk_start;
+        }
+    }
+    if (acc.y_lbody) {
+        atomicAdd(&g_ydbg[0], acc.y_fin); atomicAdd(&g_ydbg[1], acc.y_prims); atomicAdd(&g_ydbg[2], acc.y_witers); atomicAdd(&g_ydbg[3], acc.y_liters);
+        atomicAdd(&g_ydbg[4], acc.y_wbody); atomicAdd(&g_ydbg[5], acc.y_lbody);
+    }
+    // step counts live in whichever lane was first active: sum them per wave (after lane 0's plain stores above)
+    __threadfence();
+    if (wg < 8192) {
+        unsigned long long* o = g_wave_dbg[wg];
+        if (acc.wave_outer) atomicAdd(&o[7], acc.wave_outer);
+        if (acc.wave_node_steps) { atomicAdd(&o[8], acc.wave_node_steps); atomicAdd(&o[13], acc.lane_node_steps); }
+        if (acc.wave_tri_steps) { atomicAdd(&o[9], acc.wave_tri_steps); atomicAdd(&o[14], acc.lane_tri_steps); }
+    }
+}
 #endif
 
 // FindClosestHit's search part (raytracer.cpp:405-444) for generation `gen`.

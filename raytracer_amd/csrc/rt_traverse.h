@@ -127,6 +127,9 @@
 #ifndef RT_EARLY_FINISH
 #define RT_EARLY_FINISH 1        // a ray whose stack runs empty in the transition pass is retired in that pass
 #endif
+#ifndef RT_OB_BATCH
+#define RT_OB_BATCH 2            // the fields the transitions read of an object come in one batch of loads: 1 entering, 2 also leaving (0: field by field)
+#endif
 #ifndef RT_MIXED_PARTS
 #define RT_MIXED_PARTS 1         // the mixed launches' cursor is partitioned like the others' (0: one cursor)
 #endif
@@ -172,6 +175,8 @@ struct TraceStatsAcc {
     unsigned long long tl_rounds, tl_sched, tl_node, tl_tri, tl_big, tl_trans;   // after the cursor was drained
     unsigned long long clk_start, r_node_w, r_node_l, r_tri_w, r_tri_l;   // activity histogram (flushed every round)
     unsigned long long t_sched, t_node, t_tri, t_big, t_trans, clk_exhausted, n_donations, n_coop, n_replays, n_elig, n_gate, n_casfail, n_claim, n_culled;
+    unsigned long long x_block, x_retire, x_refill, x_passes;   // parts of t_trans
+    unsigned long long y_fin, y_prims, y_pop, y_witers, y_liters, y_wbody, y_lbody;   // inside the transition block (kept by the first active lane)
 };
 #define RT_CLK(v) const unsigned long long v = wall_clock64()
 #define RT_STAT(x) x
@@ -957,9 +962,11 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         RT_CLK(c4);
         RT_TLC(q4);
         for (int tpass = 0;; tpass++) {
+        RT_CLK(xa);
         bool finished = fin;
         if (alive && !fin) do {
             if (!(cur & RT_LINK_LEAF)) break;          // still on an interior record (the node phase was left early)
+            RT_STAT(const unsigned long long y0 = wall_clock64(); { st.acc->y_lbody++; if ((int)lane == __ffsll((unsigned long long)__ballot(1)) - 1) st.acc->y_wbody++; })
             if (in_mesh) {
                 if (cur != RT_LINK_SENTINEL) {
                     // a mesh leaf is waiting (queue was full): it was accepted with an older minT, re-check it
@@ -1023,7 +1030,16 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     // ---- mesh traversal finished (IntersectMeshBVH returned), raytracer.cpp:596-620
                     no_donate = false;
                     if (mesh_found) {
+#if RT_OB_BATCH > 1
+                        DObject ob;                            // transform, motion and flags in one batch of loads
+                        {
+                            const float4* src = reinterpret_cast<const float4*>(&S.objects[cur_obj]);
+                            float4* dst = reinterpret_cast<float4*>(&ob);
+                            dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; dst[8] = src[8];
+                        }
+#else
                         const DObject& ob = S.objects[cur_obj];
+#endif
                         float wt = world_t(ob, ro, time, mk(ar.ox, ar.oy, ar.oz), mk(ar.dx, ar.dy, ar.dz), tmax);
                         if (wt < minT) {
                             if (RT_ISANY) { fin = true; finished = true; break; }
@@ -1045,12 +1061,28 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             }
 
             // ---- prims of the current top-level leaf, in order (raytracer.cpp:548-745)
+            RT_STAT(const unsigned long long y1 = wall_clock64(); if ((int)lane == __ffsll((unsigned long long)__ballot(1)) - 1) st.acc->y_fin += y1 - y0;)
             bool entered = false;
             while (top_remaining != 0) {
+                RT_STAT({ st.acc->y_liters++; if ((int)lane == __ffsll((unsigned long long)__ballot(1)) - 1) st.acc->y_witers++; })
                 const DTopPrim tp = S.top_prims[top_slot];
                 top_slot++;
                 top_remaining--;
+#if RT_OB_BATCH
+                // the object's transform, motion, flags, root link and root box in one batch of loads (read field by
+                // field, each load waits behind the branch that needs it: four round trips instead of one)
+                const DObject& obg = S.objects[tp.obj];
+                DObject ob;
+                {
+                    const float4* src = reinterpret_cast<const float4*>(&obg);
+                    float4* dst = reinterpret_cast<float4*>(&ob);
+#pragma unroll
+                    for (int k = 4; k <= 10; k++) dst[k] = src[k];
+                }
+#else
                 const DObject& ob = S.objects[tp.obj];
+                const DObject& obg = ob;
+#endif
                 V3 to, td;
                 float testMinT;
                 object_space_ray(ob, ro, rd, time, minT, to, td, testMinT);
@@ -1078,8 +1110,8 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     ActiveRay sr;
                     sr.set(to, td);
                     float t;
-                    if (sphere_test(sr, ob.p[0], ob.p[1], ob.p[2], ob.p[3], testMinT, t)) {
-                        float wt = world_t(ob, ro, time, to, td, t);
+                    if (sphere_test(sr, obg.p[0], obg.p[1], obg.p[2], obg.p[3], testMinT, t)) {
+                        float wt = world_t(obg, ro, time, to, td, t);
                         if (wt < minT) {
                             if (RT_ISANY) { fin = true; break; }
                             minT = wt;
@@ -1093,9 +1125,9 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     ActiveRay tr;
                     tr.set(to, td);
                     float t, bb, gg;
-                    if (tri_test(tr, ob.p[0], ob.p[1], ob.p[2], ob.p[3], ob.p[4], ob.p[5], ob.p[6], ob.p[7], ob.p[8],
+                    if (tri_test(tr, obg.p[0], obg.p[1], obg.p[2], obg.p[3], obg.p[4], obg.p[5], obg.p[6], obg.p[7], obg.p[8],
                                  testMinT, t, bb, gg)) {
-                        float wt = world_t(ob, ro, time, to, td, t);
+                        float wt = world_t(obg, ro, time, to, td, t);
                         if (wt < minT) {
                             if (RT_ISANY) { fin = true; break; }
                             minT = wt;
@@ -1107,6 +1139,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     }
                 }
             }
+            RT_STAT(const unsigned long long y2 = wall_clock64(); if ((int)lane == __ffsll((unsigned long long)__ballot(1)) - 1) st.acc->y_prims += y2 - y1;)
             if (fin) { finished = true; break; }
             if (!entered) {
                 cur = st.pop(tmax, cur_t);
@@ -1115,6 +1148,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 if (RT_EARLY_FINISH && cur == RT_LINK_DONE) finished = true;
             }
         } while (0);
+        RT_CLK(xb);
 
         if (alive && finished) {
             if (helper) {
@@ -1144,6 +1178,8 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             st.sp = 0;
         }
         if constexpr (MEGA) io.flush(lane, lanes_below);   // finished rays: hits to the shading wave, the others off the workgroup's count
+        RT_CLK(xc);
+        RT_STAT(st.acc->x_block += xb - xa; st.acc->x_retire += xc - xb; st.acc->x_passes++;)
         if (tpass >= RT_REFILL_PASSES || (exhausted && !MEGA)) break;
         // ---- refill idle lanes
         bool refilled = false;
@@ -1331,6 +1367,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 }
             }
         }
+        RT_STAT(st.acc->x_refill += wall_clock64() - xc;)
         if (!refilled) break;
         }
         RT_TL(if (MODE == RT_TIMELINE && exhausted && any_alive) { const unsigned long long q5 = (unsigned long long)wall_clock64(); tlt[0] += q1 - q0; tlt[1] += q2 - q1; tlt[2] += q3 - q2; tlt[3] += q4 - q3; tlt[4] += q5 - q4; tlt[5]++; })
