@@ -87,6 +87,15 @@ struct DTopPrim {
     uint32_t obj;         // index into DScene::objects
 };
 
+// The top level as the reference walks it (IntersectTopBVH, raytracer.cpp:526-745: a stack, left child before right, each
+// node's box tested when it is popped): the nodes of the top BVH in pre-order, every leaf followed by its prims.  An item
+// is 32 bytes (two uint4).  Node: words 0-5 bmin.xyz, bmax.xyz, word 6 the index of the item after the node's subtree
+// (where the walk goes on when the box is missed), word 7 RT_TOPITEM_NODE.  Prim: words 0-2 kind, index inside its kind,
+// index into DScene::objects, word 7 RT_TOPITEM_PRIM.  A lane's whole top-level state is one item index.
+#define RT_TOPITEM_NODE 0u
+#define RT_TOPITEM_PRIM 1u
+#define RT_LINK_TOPSCAN 0xFFFFFFFCu   // `cur` of a ray that is between objects: its place is the item index, not a link
+
 struct DMaterial {
     uint32_t type;
     float ka[3], kd[3], ks[3], km[3];
@@ -106,6 +115,8 @@ struct DScene {
     const uint32_t*   tri_rank;      // NULL, or per triangle record its position in the reference's leaf order (rebuilt BVHs, rt_rebuild.h)
     const DObject*    objects;
     const DTopPrim*   top_prims;
+    const uint4*      top_items;     // 2 per item (see RT_TOPITEM_*)
+    uint32_t          n_top_items;
     const DPlane*     planes;
     const DMaterial*  materials;
     const DPointLight* point_lights;

@@ -112,7 +112,7 @@ struct rt_scene {
     int blocks_closest = 0, blocks_shadow = 0, blocks_ordered = 0;   // persistent grid sizes
 
     // device scene
-    DevBuf b_big, b_nodes, b_tris, b_tri_shade, b_vnormals, b_objects, b_top_prims, b_planes, b_materials, b_lights, b_area_lights;
+    DevBuf b_big, b_nodes, b_tris, b_tri_shade, b_vnormals, b_objects, b_top_prims, b_top_items, b_planes, b_materials, b_lights, b_area_lights;
     DScene ds{};
     DevBuf b_tri_rank;                // rebuilt mesh BVHs only (rt_rebuild.h)
     bool rebuilt = false;             // uploaded with RT_UPLOAD_REBUILD_MESH_BVH: always traced nearest-first
@@ -676,6 +676,37 @@ int build_top_level(rt_scene* sc, const rt_scene_desc* s) {
         const rt_bvh_node& n = s->top_nodes[i];
         for (int32_t k = 0; k < n.prim_count; k++) top[n.left_or_first + k].remaining = (uint32_t)(n.prim_count - k);
     }
+    // the top level in the reference's visiting order: nodes in pre-order, a leaf's prims behind it (rt_device.h: RT_TOPITEM_*)
+    std::vector<uint4> items;
+    if (s->n_top_prims != 0) {
+        items.reserve(2 * ((size_t)s->n_top_nodes + s->n_top_prims));
+        struct Visit { uint32_t node; uint32_t item; bool close; };
+        std::vector<Visit> work{{0u, 0u, false}};
+        while (!work.empty()) {
+            const Visit v = work.back();
+            work.pop_back();
+            if (v.close) { items[2 * (size_t)v.item + 1].z = (uint32_t)(items.size() / 2); continue; }
+            const rt_bvh_node& n = s->top_nodes[v.node];
+            const uint32_t at = (uint32_t)(items.size() / 2);
+            uint4 a, b;
+            std::memcpy(&a.x, &n.bmin[0], 4); std::memcpy(&a.y, &n.bmin[1], 4); std::memcpy(&a.z, &n.bmin[2], 4); std::memcpy(&a.w, &n.bmax[0], 4);
+            std::memcpy(&b.x, &n.bmax[1], 4); std::memcpy(&b.y, &n.bmax[2], 4);
+            b.z = 0u; b.w = RT_TOPITEM_NODE;
+            items.push_back(a); items.push_back(b);
+            work.push_back({0u, at, true});                 // (runs after the subtree: the item that follows it)
+            if (n.prim_count > 0) {
+                for (int32_t k = 0; k < n.prim_count; k++) {
+                    const DTopPrim& tp = top[n.left_or_first + k];
+                    items.push_back(make_uint4(tp.kind, tp.index, tp.obj, 0u));
+                    items.push_back(make_uint4(0u, 0u, 0u, RT_TOPITEM_PRIM));
+                }
+            } else {
+                work.push_back({(uint32_t)n.left_or_first + 1u, 0u, false});
+                work.push_back({(uint32_t)n.left_or_first, 0u, false});
+            }
+        }
+    }
+    if (items.size() / 2 >= 0x7FFFFFFFu) return fail(RT_ERR_UNSUPPORTED, "top level too large");
     BvhLayout TL = layout_bvh(s->top_nodes, s->n_top_prims ? s->n_top_nodes : 0, 0, true, nodes, big, M.n_node_records);
     // one stack per ray holds the top-level entries, the sentinel and the mesh level (rt_traverse.h)
     const uint32_t stack_need = stack_need_of_depth(bvh_depth(s->top_nodes, s->n_top_prims ? s->n_top_nodes : 0)) + 1u + sc->mesh_stack_need + 2u;
@@ -730,7 +761,7 @@ int build_top_level(rt_scene* sc, const rt_scene_desc* s) {
     if ((rc = sc->b_nodes.grow_keep(((size_t)M.n_node_records + nodes.size()) * sizeof(DNode4), (size_t)M.n_node_records * sizeof(DNode4)))) return rc;
     if (!nodes.empty())
         HIPCHK(hipMemcpy((DNode4*)sc->b_nodes.p + M.n_node_records, nodes.data(), nodes.size() * sizeof(DNode4), hipMemcpyHostToDevice));
-    if ((rc = upload_vec(sc->b_objects, objects)) || (rc = upload_vec(sc->b_top_prims, top)) ||
+    if ((rc = upload_vec(sc->b_objects, objects)) || (rc = upload_vec(sc->b_top_prims, top)) || (rc = upload_vec(sc->b_top_items, items)) ||
         (rc = upload_vec(sc->b_big, big)) || (rc = upload_vec(sc->b_planes, planes)) || (rc = upload_vec(sc->b_materials, mats)) || (rc = upload_vec(sc->b_lights, lights)))
         return rc;
 
@@ -743,6 +774,8 @@ int build_top_level(rt_scene* sc, const rt_scene_desc* s) {
     if (getenv("RT_NO_DONATE")) D.donate_ok = 0u;      // diagnostic: every ray is traced by its owner alone
     D.objects = (const DObject*)sc->b_objects.p;
     D.top_prims = (const DTopPrim*)sc->b_top_prims.p;
+    D.top_items = (const uint4*)sc->b_top_items.p;
+    D.n_top_items = (uint32_t)(items.size() / 2);
     D.planes = (const DPlane*)sc->b_planes.p;
     D.materials = (const DMaterial*)sc->b_materials.p;
     D.point_lights = (const DPointLight*)sc->b_lights.p;
@@ -1629,7 +1662,7 @@ void rt_free_scene(rt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    for (DevBuf* b : {&s->b_big, &s->b_nodes, &s->b_tris, &s->b_tri_shade, &s->b_vnormals, &s->b_objects, &s->b_top_prims, &s->b_planes,
+    for (DevBuf* b : {&s->b_big, &s->b_nodes, &s->b_tris, &s->b_tri_shade, &s->b_vnormals, &s->b_objects, &s->b_top_prims, &s->b_top_items, &s->b_planes,
                       &s->b_materials, &s->b_lights, &s->b_ray0, &s->b_ray1, &s->b_hit0, &s->b_hit1, &s->b_nrm, &s->b_link,
                       &s->b_color, &s->b_shadow_rec, &s->b_shadow_lit, &s->b_ctl, &s->b_spill, &s->b_cand, &s->b_mt, &s->b_frames, &s->b_pstate, &s->b_tile_order, &s->b_area_lights, &s->b_fb, &s->b_hits, &s->b_tri_rank, &s->b_wq, &s->b_sq})
         b->release();

@@ -127,6 +127,9 @@
 #ifndef RT_EARLY_FINISH
 #define RT_EARLY_FINISH 1        // a ray whose stack runs empty in the transition pass is retired in that pass
 #endif
+#ifndef RT_FLAT_TOP
+#define RT_FLAT_TOP 1            // the top level is walked in the transition block, item by item (rt_device.h: RT_TOPITEM_*); 0: as 4-wide records in the node phase
+#endif
 #ifndef RT_OB_BATCH
 #define RT_OB_BATCH 2            // the fields the transitions read of an object come in one batch of loads: 1 entering, 2 also leaving (0: field by field)
 #endif
@@ -418,7 +421,10 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
     ar.set(ro, rd);
     float tmax = 0.f;            // culling bound of the active level
     bool in_mesh = false;
-    uint32_t top_slot = 0, top_remaining = 0;
+    uint32_t top_slot = 0;       // the ray's place in the top level: the next item (RT_FLAT_TOP), or the next slot of the leaf it is in
+#if !RT_FLAT_TOP
+    uint32_t top_remaining = 0;
+#endif
     uint32_t cur_obj = 0;        // state of the mesh traversal in flight
     bool mesh_found = false;
     uint32_t mesh_tri = 0;
@@ -1025,7 +1031,9 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 if (redo) {
                     no_donate = true;
                     top_slot--;
+#if !RT_FLAT_TOP
                     top_remaining++;
+#endif
                 } else {
                     // ---- mesh traversal finished (IntersectMeshBVH returned), raytracer.cpp:596-620
                     no_donate = false;
@@ -1056,18 +1064,40 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 tmax = minT;
             } else {
                 if (cur == RT_LINK_DONE) { finished = true; break; }   // traversal exhausted
+#if !RT_FLAT_TOP
                 top_slot = RT_LEAF_FIRST(cur);
                 top_remaining = leaf_count(S, cur, true);
+#endif
             }
 
             // ---- prims of the current top-level leaf, in order (raytracer.cpp:548-745)
             RT_STAT(const unsigned long long y1 = wall_clock64(); if ((int)lane == __ffsll((unsigned long long)__ballot(1)) - 1) st.acc->y_fin += y1 - y0;)
             bool entered = false;
+#if RT_FLAT_TOP
+            // The top level itself is walked here, in the reference's order (IntersectTopBVH, raytracer.cpp:536-745: the nodes
+            // in pre-order, a node's box tested with the minT of the moment it is popped, its subtree skipped on a miss): one
+            // item per turn of this loop, a node or a prim of the leaf before it.  `ar` is the world ray here.  (As 4-wide
+            // records in the node phase, every top-level leaf cost the ray a round of its wave.)
+            while (top_slot < S.n_top_items) {
+                RT_STAT({ st.acc->y_liters++; if ((int)lane == __ffsll((unsigned long long)__ballot(1)) - 1) st.acc->y_witers++; })
+                const uint4 it0 = S.top_items[2u * top_slot], it1 = S.top_items[2u * top_slot + 1u];
+                if (it1.w == RT_TOPITEM_NODE) {
+                    float te_;
+                    const bool hit_ = box_test(ar, __uint_as_float(it0.x), __uint_as_float(it0.y), __uint_as_float(it0.z), __uint_as_float(it0.w),
+                                               __uint_as_float(it1.x), __uint_as_float(it1.y), minT, te_);
+                    top_slot = hit_ ? top_slot + 1u : it1.z;
+                    continue;
+                }
+                top_slot++;
+                DTopPrim tp;
+                tp.kind = it0.x; tp.index = it0.y; tp.obj = it0.z; tp.remaining = 0;
+#else
             while (top_remaining != 0) {
                 RT_STAT({ st.acc->y_liters++; if ((int)lane == __ffsll((unsigned long long)__ballot(1)) - 1) st.acc->y_witers++; })
                 const DTopPrim tp = S.top_prims[top_slot];
                 top_slot++;
                 top_remaining--;
+#endif
 #if RT_OB_BATCH
                 // the object's transform, motion, flags, root link and root box in one batch of loads (read field by
                 // field, each load waits behind the branch that needs it: four round trips instead of one)
@@ -1263,7 +1293,12 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     if (S.top_root_link != RT_LINK_DONE) {
                         float te;
                         if (box_test(ar, S.top_rmin[0], S.top_rmin[1], S.top_rmin[2], S.top_rmax[0], S.top_rmax[1], S.top_rmax[2], tmax, te)) {
+#if RT_FLAT_TOP
+                            cur = RT_LINK_TOPSCAN;
+                            top_slot = 1;                        // (item 0 is the root node: its box is the one just tested)
+#else
                             cur = S.top_root_link;
+#endif
                             cur_t = te;
                         }
                     }
@@ -1360,7 +1395,12 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     if (S.top_root_link != RT_LINK_DONE) {
                         float te;
                         if (box_test(ar, S.top_rmin[0], S.top_rmin[1], S.top_rmin[2], S.top_rmax[0], S.top_rmax[1], S.top_rmax[2], tmax, te)) {
+#if RT_FLAT_TOP
+                            cur = RT_LINK_TOPSCAN;
+                            top_slot = 1;                        // (item 0 is the root node: its box is the one just tested)
+#else
                             cur = S.top_root_link;
+#endif
                             cur_t = te;
                         }
                     }
