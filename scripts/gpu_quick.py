@@ -12,6 +12,27 @@ cases = [
     ("inst10 8K", lambda: scenes.instanced_scene(709, 7680, 4320)),
     ("glossy 1080p 16spp", lambda: scenes.glossy_area_scene(256, 1920, 1080, 16)),
 ]
+def many_spheres(n_side, width=1920, height=1080):
+    """A large top level: n_side x n_side spheres on a plane (top BVH of ~2 n^2 nodes), two point lights, a mirror floor."""
+    import numpy as np
+    from raytracer_amd import ffi
+    s = scenes.SynthScene(f"spheres{n_side}")
+    s.max_depth = 2
+    verts = [(-40.0, -1.0, -40.0)]
+    rng = np.random.default_rng(7)
+    for i in range(n_side):
+        for j in range(n_side):
+            verts.append((float((i - n_side / 2) * 1.0 + rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.3, 0.3)), float((j - n_side / 2) * 1.0 + rng.uniform(-0.2, 0.2))))
+    s.vertices = verts
+    s.materials = [dict(ambient=(1, 1, 1), diffuse=(0.8, 0.4, 0.3), specular=(1, 1, 1), phong=30.0),
+                   dict(type=ffi.RT_MAT_MIRROR, ambient=(0.1, 0.1, 0.1), diffuse=(0.3, 0.3, 0.3), specular=(1, 1, 1), mirror=(0.6, 0.6, 0.6), phong=80.0)]
+    s.point_lights = [((10, 30, 20), (400000, 400000, 400000)), ((-20, 15, 5), (150000, 150000, 200000))]
+    s.spheres = [dict(center=k + 2, radius=0.35, material=1 + (k % 7 == 0)) for k in range(n_side * n_side)]
+    s.planes = [dict(point=1, normal=(0, 1, 0), material=1)]
+    d = n_side * 0.55
+    s.camera = dict(position=(0.0, d * 0.6, d), gaze_point=(0, 0, 0), up=(0, 1, 0), fovy=45.0, near=1.0, width=width, height=height, num_samples=1)
+    return s
+cases += [("spheres 30x30", lambda: many_spheres(30)), ("spheres 200x200", lambda: many_spheres(200))]
 sel = sys.argv[1:] or ["mesh1m 1080p", "inst10 1080p"]
 iters = int(os.environ.get("RT_QUICK_ITERS", "8"))
 flags = int(os.environ.get("RT_QUICK_FLAGS", "0"))
