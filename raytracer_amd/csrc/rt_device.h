@@ -94,6 +94,16 @@ struct DTopPrim {
 // index into DScene::objects, word 7 RT_TOPITEM_PRIM.  A lane's whole top-level state is one item index.
 #define RT_TOPITEM_NODE 0u
 #define RT_TOPITEM_PRIM 1u
+// RT_INLINE_LEAF_MESH: an instance of a mesh whose BVH is one leaf of at most RT_INLINE_LEAF_MAX triangles, without
+// transformation or motion blur (a ground quad, a wall), is written as a node item with the mesh's root box followed by one
+// RT_KIND_MESHTRI item per triangle (word 3: the triangle's slot in DScene::tris).  For such an instance the reference's
+// IntersectMeshBVH (raytracer.cpp:758-811) is: the root box against minT, then each triangle against the running bound, then
+// `t < minT` — which is what the walk does with these items, on the same operands (testRay == ray, testMinT == minT, worldT == t).
+#ifndef RT_INLINE_LEAF_MESH
+#define RT_INLINE_LEAF_MESH 1
+#endif
+#define RT_INLINE_LEAF_MAX 4
+#define RT_KIND_MESHTRI 4u
 #define RT_LINK_TOPSCAN 0xFFFFFFFCu   // `cur` of a ray that is between objects: its place is the item index, not a link
 
 struct DMaterial {

@@ -679,7 +679,7 @@ int build_top_level(rt_scene* sc, const rt_scene_desc* s) {
     // the top level in the reference's visiting order: nodes in pre-order, a leaf's prims behind it (rt_device.h: RT_TOPITEM_*)
     std::vector<uint4> items;
     if (s->n_top_prims != 0) {
-        items.reserve(2 * ((size_t)s->n_top_nodes + s->n_top_prims));
+        items.reserve(2 * ((size_t)s->n_top_nodes + (size_t)s->n_top_prims * (1 + RT_INLINE_LEAF_MAX)));
         struct Visit { uint32_t node; uint32_t item; bool close; };
         std::vector<Visit> work{{0u, 0u, false}};
         while (!work.empty()) {
@@ -697,6 +697,22 @@ int build_top_level(rt_scene* sc, const rt_scene_desc* s) {
             if (n.prim_count > 0) {
                 for (int32_t k = 0; k < n.prim_count; k++) {
                     const DTopPrim& tp = top[n.left_or_first + k];
+                    const DObject& o = objects[tp.obj];
+                    const uint32_t leaf_n = RT_LEAF_COUNT(o.root_link);
+                    if (RT_INLINE_LEAF_MESH && tp.kind == RT_KIND_MESH && !(o.flags & (RT_OBJ_HAS_TRANSFORM | RT_OBJ_HAS_MOTION_BLUR)) &&
+                        (o.root_link & RT_LINK_LEAF) && o.root_link < RT_LINK_TOPSCAN && leaf_n >= 1 && leaf_n <= RT_INLINE_LEAF_MAX) {
+                        // the instance's root box as a node of its own, its triangles behind it (rt_device.h: RT_INLINE_LEAF_MESH)
+                        uint4 a, b;
+                        std::memcpy(&a.x, &o.rminx, 4); std::memcpy(&a.y, &o.rminy, 4); std::memcpy(&a.z, &o.rminz, 4); std::memcpy(&a.w, &o.rmaxx, 4);
+                        std::memcpy(&b.x, &o.rmaxy, 4); std::memcpy(&b.y, &o.rmaxz, 4);
+                        b.z = (uint32_t)(items.size() / 2) + 1u + leaf_n; b.w = RT_TOPITEM_NODE;
+                        items.push_back(a); items.push_back(b);
+                        for (uint32_t j = 0; j < leaf_n; j++) {
+                            items.push_back(make_uint4(RT_KIND_MESHTRI, tp.index, tp.obj, RT_LEAF_FIRST(o.root_link) + j));
+                            items.push_back(make_uint4(0u, 0u, 0u, RT_TOPITEM_PRIM));
+                        }
+                        continue;
+                    }
                     items.push_back(make_uint4(tp.kind, tp.index, tp.obj, 0u));
                     items.push_back(make_uint4(0u, 0u, 0u, RT_TOPITEM_PRIM));
                 }

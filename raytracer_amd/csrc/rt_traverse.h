@@ -1151,19 +1151,27 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                             tmax = minT;
                         }
                     }
-                } else {   // RT_KIND_TRIANGLE
+                } else {   // RT_KIND_TRIANGLE; or RT_KIND_MESHTRI, a triangle of a one-leaf mesh written into the walk (rt_device.h)
                     ActiveRay tr;
                     tr.set(to, td);
                     float t, bb, gg;
-                    if (tri_test(tr, obg.p[0], obg.p[1], obg.p[2], obg.p[3], obg.p[4], obg.p[5], obg.p[6], obg.p[7], obg.p[8],
-                                 testMinT, t, bb, gg)) {
+#if RT_FLAT_TOP && RT_INLINE_LEAF_MESH
+                    const bool of_mesh = tp.kind == RT_KIND_MESHTRI;
+                    const float* tq = of_mesh ? reinterpret_cast<const float*>(&S.tris[it0.w]) : &obg.p[0];
+#else
+                    const bool of_mesh = false;
+                    const float* tq = &obg.p[0];
+#endif
+                    if (tri_test(tr, tq[0], tq[1], tq[2], tq[3], tq[4], tq[5], tq[6], tq[7], tq[8], testMinT, t, bb, gg)) {
                         float wt = world_t(obg, ro, time, to, td, t);
                         if (wt < minT) {
                             if (RT_ISANY) { fin = true; break; }
                             minT = wt;
                             has = true;
-                            out.kind_index = (RT_KIND_TRIANGLE << 28) | tp.index;
-                            out.tri = 0;
+                            out.kind_index = ((of_mesh ? RT_KIND_MESH : RT_KIND_TRIANGLE) << 28) | tp.index;
+                            out.tri = of_mesh ? it0.w : 0u;
+                            out.beta = of_mesh ? bb : out.beta;
+                            out.gamma = of_mesh ? gg : out.gamma;
                             tmax = minT;
                         }
                     }

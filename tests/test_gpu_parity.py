@@ -549,6 +549,20 @@ def test_degenerate_scenes_vs_oracle(rt):
     s.instances = [dict(base=0, material=1, transform=[("s", (0.25, 0.25, 0.25)), ("t", (0.0, 0.0, 1.0))], reset=False)]
     s.camera = dict(cam, width=33, height=33)      # odd size: the centre pixel looks straight down -z unless jittered
     cases.append(s)
+    # one-leaf meshes next to each other in the top level: an untransformed smooth quad and a flat one (both written into the top-level
+    # walk as triangles, rt_device.h: RT_INLINE_LEAF_MESH), a transformed copy and a moving one (both entered as meshes), a sphere
+    # in front of them and a mirror plane under them — hits, barycentrics (smooth normals) and the order in which equal candidates win
+    s = base("one_leaf_meshes_mixed")
+    s.vertices += [(-1.5, -0.5, -0.5), (1.5, -0.5, -0.5), (1.5, 1.2, -0.8), (-1.5, 1.2, -0.8), (0.2, 0.1, 0.4)]
+    s.point_lights = [((2, 4, 3), (30000, 30000, 30000)), ((-3, 2, 4), (15000, 15000, 20000))]
+    s.planes = [dict(point=1, normal=(0, 1, 0), material=2)]
+    s.meshes = [dict(verts=None, faces=np.array([[5, 6, 7], [5, 7, 8]], np.int32), material=1, smooth=True),
+                dict(verts=None, faces=np.array([[2, 3, 4], [2, 4, 8]], np.int32), material=2),
+                dict(verts=None, faces=np.array([[5, 6, 7], [5, 7, 8]], np.int32), material=1, transform=[("t", (0.3, 0.2, 0.6)), ("r", (20.0, 0, 1, 0))])]
+    s.instances = [dict(base=0, material=2, transform=[("s", (0.5, 0.5, 0.5)), ("t", (-0.8, 0.3, 1.2))], reset=False)]
+    s.spheres = [dict(center=9, radius=0.3, material=1)]
+    s.camera = dict(cam, width=97, height=65)
+    cases.append(s)
     for spec in cases:
         _vs_oracle(rt, spec)
 
