@@ -192,7 +192,10 @@ __device__ __forceinline__ V3 xf_point(const float* m, V3 p) {
     float y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7] * 1;
     float z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11] * 1;
     float w = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15] * 1;
-    return mk(x / w, y / w, z / w);
+    // (x / 1.0f is x, bit for bit, for every x: with the affine matrices the parser composes w is exactly 1 and the three
+    // IEEE divisions — the reference makes them, Mat4f.h — are skipped by a branch no lane takes)
+    if (w != 1.0f) { x = x / w; y = y / w; z = z / w; }
+    return mk(x, y, z);
 }
 // Mat4f.h:30-36
 __device__ __forceinline__ V3 xf_vector(const float* m, V3 v) {
