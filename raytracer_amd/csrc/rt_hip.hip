@@ -724,8 +724,13 @@ int build_top_level(rt_scene* sc, const rt_scene_desc* s) {
     }
     if (items.size() / 2 >= 0x7FFFFFFFu) return fail(RT_ERR_UNSUPPORTED, "top level too large");
     BvhLayout TL = layout_bvh(s->top_nodes, s->n_top_prims ? s->n_top_nodes : 0, 0, true, nodes, big, M.n_node_records);
-    // one stack per ray holds the top-level entries, the sentinel and the mesh level (rt_traverse.h)
+    // one stack per ray: the sentinel and the mesh level (and, without RT_FLAT_TOP, the top-level entries below them)
+#if RT_FLAT_TOP
+    // (the top level is walked without a stack, rt_traverse.h: only the sentinel and the mesh level are on it)
+    const uint32_t stack_need = 1u + sc->mesh_stack_need + 2u;
+#else
     const uint32_t stack_need = stack_need_of_depth(bvh_depth(s->top_nodes, s->n_top_prims ? s->n_top_nodes : 0)) + 1u + sc->mesh_stack_need + 2u;
+#endif
     if (stack_need > RT_STACK_CAP_LIMIT)
         return fail(RT_ERR_UNSUPPORTED, "BVH too deep: a ray could need %u traversal stack entries (limit %d)", stack_need, RT_STACK_CAP_LIMIT);
     sc->stack_cap_derived = std::max<uint32_t>(RT_STACK_MIN_CAP, stack_need);
