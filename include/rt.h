@@ -227,8 +227,8 @@ typedef struct rt_stats {
     float    ms_closest;       /* sum over launches of the closest-hit kernel    */
     float    ms_shade;
     float    ms_shadow;        /* sum over launches of the any-hit kernel        */
-    float    ms_combine;
-    float    ms_resolve;
+    float    ms_combine;       /* the bottom-up colour pass of the generations above 0 (0 on a depth-0 frame)  */
+    float    ms_resolve;       /* generation 0's colours, the sum over a pixel's samples, clamp, RGB8          */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;   /* opaque, library-owned, one per GPU */

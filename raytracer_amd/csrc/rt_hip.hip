@@ -1229,11 +1229,12 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
             }
         }
         if ((rc = tm.begin(TC_COMBINE))) return rc;
-        for (int d = D; d >= 0; d--) k_combine<<<grid_flat, 256, 0, st>>>(sc->ds, P, ctl, d);
+        for (int d = D; d >= 1; d--) k_combine<<<grid_flat, 256, 0, st>>>(sc->ds, P, ctl, d);   // (generation 0: in k_resolve)
         if ((rc = tm.end())) return rc;
         }
         if ((rc = tm.begin(TC_RESOLVE))) return rc;
-        k_resolve<<<(g.n_idx + 255) / 256, 256, 0, st>>>(dc, g, P, sc->ds.tri_shade, inv_n, d_rgb, stride, d_hits);
+        if (mega) k_resolve<false><<<(g.n_idx + 255) / 256, 256, 0, st>>>(sc->ds, dc, g, P, sc->ds.tri_shade, inv_n, d_rgb, stride, d_hits);
+        else k_resolve<true><<<(g.n_idx + 255) / 256, 256, 0, st>>>(sc->ds, dc, g, P, sc->ds.tri_shade, inv_n, d_rgb, stride, d_hits);
         if ((rc = tm.end())) return rc;
         HIPCHK(hipGetLastError());
         chunks++;

@@ -631,7 +631,10 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) {   // Math
 }
 
 // raytracer.cpp:77-85: sum the samples in order, scale, clamp, truncate.
-__global__ void __launch_bounds__(256) k_resolve(DCamera cam, ChunkGeom g, Pool P, const DTriShade* tri_shade, float inv_n,
+// COMBINE0: the records of generation 0 — the pixel's own samples, idx * N + s — are combined here, by the thread that
+// sums them (their children are done: k_combine ran for the generations above), instead of by a launch of their own.
+template <bool COMBINE0>
+__global__ void __launch_bounds__(256) k_resolve(DScene S, DCamera cam, ChunkGeom g, Pool P, const DTriShade* tri_shade, float inv_n,
                                                  uint8_t* rgb, size_t row_stride, uint32_t* hit_ids) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= g.n_idx) return;
@@ -640,7 +643,9 @@ __global__ void __launch_bounds__(256) k_resolve(DCamera cam, ChunkGeom g, Pool 
     const int N = cam.num_samples;
     V3 sum = mk(0.0f, 0.0f, 0.0f);
     for (int s = 0; s < N; s++) {
-        float4 c = P.color[(size_t)idx * N + s];
+        const uint32_t r = idx * (uint32_t)N + (uint32_t)s;
+        if constexpr (COMBINE0) combine_record(S, P, r, P.link[r], 0);
+        float4 c = P.color[r];
         sum = sum + mk(c.x, c.y, c.z);
     }
     V3 c = sum * inv_n;
