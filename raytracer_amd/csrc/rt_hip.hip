@@ -1136,8 +1136,7 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
             dc1.num_samples = 1;
             dc1.sps = 1;
             if ((rc = tm.begin(TC_RAYGEN))) return rc;
-            k_init_chunk<<<1, 64, 0, st>>>(ctl, n_idx);
-            k_raygen_single<<<(n_idx + 255) / 256, 256, 0, st>>>(dc1, A.g, sc->pool);
+            k_raygen_single<<<(n_idx + 255) / 256, 256, 0, st>>>(dc1, A.g, sc->pool, ctl, n_idx);
             if (near) k_trace_closest<true><<<blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, sc->pool, ctl, 0, spill, cand);
             else k_trace_closest<false><<<blocks_closest, RT_TRACE_BLOCK, 0, st>>>(sc->ds, sc->pool, ctl, 0, spill, cand);
             k_tile_cost<<<(n_idx + 255) / 256, 256, 0, st>>>(sc->ds, sc->pool, n_idx, d_cost);
@@ -1167,15 +1166,14 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
         const uint32_t nt = std::min(tiles_per_chunk, total_tiles - tile);
         ChunkGeom g{x0, y0, w, h, tiles_per_row, tile, nt * 64u, row_parts, row_part};
         const uint32_t n_primary = g.n_idx * (uint32_t)N;
-        k_init_chunk<<<1, 64, 0, st>>>(ctl, n_primary);
         if ((rc = tm.begin(TC_RAYGEN))) return rc;
         if (N == 1) {
-            k_raygen_single<<<(g.n_idx + 255) / 256, 256, 0, st>>>(dc, g, P);
+            k_raygen_single<<<(g.n_idx + 255) / 256, 256, 0, st>>>(dc, g, P, ctl, n_primary);
         } else {
             const size_t strideT = g.n_idx;
             if (!ws && (rc = sc->b_mt.ensure(strideT * (624 + (size_t)N) * 4))) return rc;
             uint32_t* mt = ws ? ws_mt : (uint32_t*)sc->b_mt.p;
-            k_raygen_multi<<<(g.n_idx + 255) / 256, 256, 0, st>>>(dc, g, P, mt, mt + strideT * 624, strideT);
+            k_raygen_multi<<<(g.n_idx + 255) / 256, 256, 0, st>>>(dc, g, P, mt, mt + strideT * 624, strideT, ctl, n_primary);
         }
         if ((rc = tm.end())) return rc;
         const int grid_flat = 2048;

@@ -74,21 +74,22 @@ __device__ __forceinline__ void write_ray(const Pool& P, uint32_t r, V3 o, V3 d,
     P.ray1[r] = make_float4(d.x, d.y, d.z, __uint_as_float(live ? 1u : 0u));
 }
 
-__global__ void k_init_chunk(Control* ctl, uint32_t n_primary) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        for (int g = 0; g < RT_MAX_GEN + 2; g++) { ctl->gstart[g] = n_primary; ctl->sstart[g] = 0; }
-        ctl->gstart[0] = 0;
-        ctl->n_records = n_primary;
-        ctl->n_shadow = 0;
-        for (int p = 0; p < RT_PARTS; p++) { ctl->cursor_closest[p * RT_CURSOR_STRIDE] = 0; ctl->cursor_shadow[p * RT_CURSOR_STRIDE] = 0; }
-        ctl->overflow = 0;
-    }
+// Start of a chunk: generation 0 = the primary records.  Done by one thread of the ray-generation launch (nothing reads
+// the control block before the first trace launch, which follows it on the stream).
+__device__ __forceinline__ void init_chunk(Control* ctl, uint32_t n_primary) {
+    for (int g = 0; g < RT_MAX_GEN + 2; g++) { ctl->gstart[g] = n_primary; ctl->sstart[g] = 0; }
+    ctl->gstart[0] = 0;
+    ctl->n_records = n_primary;
+    ctl->n_shadow = 0;
+    for (int p = 0; p < RT_PARTS; p++) { ctl->cursor_closest[p * RT_CURSOR_STRIDE] = 0; ctl->cursor_shadow[p * RT_CURSOR_STRIDE] = 0; }
+    ctl->overflow = 0;
 }
 
 // num_samples == 1: one thread per pixel (raytracer.cpp:44-74 with N = 1: the
 // shuffle of one element draws nothing, then five draws).
-__global__ void __launch_bounds__(256) k_raygen_single(DCamera cam, ChunkGeom g, Pool P) {
+__global__ void __launch_bounds__(256) k_raygen_single(DCamera cam, ChunkGeom g, Pool P, Control* ctl, uint32_t n_primary) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0 && ctl) init_chunk(ctl, n_primary);
     if (idx >= g.n_idx) return;
     int px, py;
     if (!idx_to_pixel(g, idx, px, py)) {
@@ -112,8 +113,9 @@ __global__ void __launch_bounds__(256) k_raygen_single(DCamera cam, ChunkGeom g,
 // num_samples > 1: one thread per pixel walks its sample sequence; the rays of
 // pixel idx are records idx*N .. idx*N+N-1.
 __global__ void __launch_bounds__(256) k_raygen_multi(DCamera cam, ChunkGeom g, Pool P, uint32_t* mt_scratch,
-                                                      uint32_t* perm_scratch, size_t stride) {
+                                                      uint32_t* perm_scratch, size_t stride, Control* ctl, uint32_t n_primary) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0 && ctl) init_chunk(ctl, n_primary);
     if (idx >= g.n_idx) return;
     const int N = cam.num_samples, sps = cam.sps;
     int px, py;

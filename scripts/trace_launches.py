@@ -3,8 +3,8 @@
 import csv, glob, os, sys
 f = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-# last frame = from the last k_init_chunk on
-last = max(i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_init_chunk"))
+# last frame = from the last ray-generation launch on (a frame of one chunk)
+last = max(i for i, r in enumerate(rows) if "k_raygen" in r["Kernel_Name"])
 t0 = int(rows[last]["Start_Timestamp"])
 for r in rows[last:]:
     n = r["Kernel_Name"].split("(")[0].replace("void ", "")
