@@ -563,6 +563,18 @@ def test_degenerate_scenes_vs_oracle(rt):
     s.spheres = [dict(center=9, radius=0.3, material=1)]
     s.camera = dict(cam, width=97, height=65)
     cases.append(s)
+    # a top-level leaf the builder cannot split (40 concentric spheres: equal centroids), next to ordinary leaves: the walk takes
+    # however many prims follow a leaf node (the 4-wide records needed a side table above 30)
+    s = base("unsplittable_top_level_leaf")
+    s.vertices += [(0.3, 0.0, 0.2)]
+    s.point_lights = [((2, 4, 3), (30000, 30000, 30000))]
+    s.planes = [dict(point=1, normal=(0, 1, 0), material=1)]
+    s.materials.append(dict(type=rt.ffi.RT_MAT_DIELECTRIC, diffuse=(0.01, 0.01, 0.01), specular=(0.5, 0.5, 0.5), mirror=(1, 1, 1), phong=100.0,
+                            refraction_index=1.4, absorption_coef=(0.02, 0.05, 0.05)))
+    s.spheres = [dict(center=5, radius=0.9 - 0.02 * k, material=3 if k % 2 == 0 else 1) for k in range(40)]
+    s.meshes = [dict(verts=None, faces=np.array([[2, 3, 4]], np.int32), material=2)]
+    s.camera = dict(cam, width=81, height=49)
+    cases.append(s)
     for spec in cases:
         _vs_oracle(rt, spec)
 
