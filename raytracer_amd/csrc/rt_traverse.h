@@ -1157,9 +1157,11 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     float t, bb, gg;
 #if RT_FLAT_TOP && RT_INLINE_LEAF_MESH
                     const bool of_mesh = tp.kind == RT_KIND_MESHTRI;
-                    const float* tq = of_mesh ? reinterpret_cast<const float*>(&S.tris[it0.w]) : &obg.p[0];
+                    const uint32_t mesh_tri_slot = it0.w;
+                    const float* tq = of_mesh ? reinterpret_cast<const float*>(&S.tris[mesh_tri_slot]) : &obg.p[0];
 #else
                     const bool of_mesh = false;
+                    const uint32_t mesh_tri_slot = 0;
                     const float* tq = &obg.p[0];
 #endif
                     if (tri_test(tr, tq[0], tq[1], tq[2], tq[3], tq[4], tq[5], tq[6], tq[7], tq[8], testMinT, t, bb, gg)) {
@@ -1169,7 +1171,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                             minT = wt;
                             has = true;
                             out.kind_index = ((of_mesh ? RT_KIND_MESH : RT_KIND_TRIANGLE) << 28) | tp.index;
-                            out.tri = of_mesh ? it0.w : 0u;
+                            out.tri = of_mesh ? mesh_tri_slot : 0u;
                             out.beta = of_mesh ? bb : out.beta;
                             out.gamma = of_mesh ? gg : out.gamma;
                             tmax = minT;
