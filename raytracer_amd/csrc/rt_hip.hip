@@ -1300,6 +1300,14 @@ int render_impl(rt_scene* sc, const rt_camera_desc* cam, int x0, int y0, int w, 
             if (hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_tl_tail), sizeof(tt)) == hipSuccess && tt[5]) {
                 fprintf(stderr, "[rt tl tail] %llu rounds of waves with rays after the drain: per round sched %.2f node %.2f tri %.2f big %.2f trans+refill %.2f us\n", tt[5],
                         tt[0] * 0.01 / tt[5], tt[1] * 0.01 / tt[5], tt[2] * 0.01 / tt[5], tt[3] * 0.01 / tt[5], tt[4] * 0.01 / tt[5]);
+                unsigned long long t2[8] = {0};
+                if (hipMemcpyFromSymbol(t2, HIP_SYMBOL(g_tl_tail2), sizeof(t2)) == hipSuccess) {
+                    fprintf(stderr, "[rt tl tail] per round: sched = claim %.2f + announce %.2f + post %.2f + rest %.2f us; transitions = block %.2f + retire %.2f us (all passes) | %llu replays, %.2f candidates each\n",
+                            t2[0] * 0.01 / tt[5], t2[1] * 0.01 / tt[5], t2[2] * 0.01 / tt[5], t2[3] * 0.01 / tt[5], t2[4] * 0.01 / tt[5], t2[5] * 0.01 / tt[5],
+                            t2[6], t2[6] ? (double)t2[7] / t2[6] : 0.0);
+                    std::memset(t2, 0, sizeof(t2));
+                    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_tail2), t2, sizeof(t2));
+                }
                 std::memset(tt, 0, sizeof(tt));
                 (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_tail), tt, sizeof(tt));
             }

@@ -216,6 +216,7 @@ __device__ unsigned long long g_tl_t0 = ~0ull;
 __device__ uint32_t g_tl_log[RT_TL_LOG][8];
 __device__ uint32_t g_tl_log_n;
 __device__ unsigned long long g_tl_tail[8];   // after the drain, summed over waves with rays: ticks in sched / node / tri / big / transitions, rounds
+__device__ unsigned long long g_tl_tail2[8];  // the same rounds: sched = claim / announce / post / rest; transitions = block / retire; replays, candidates
 #define RT_TLC(v) const unsigned long long v = (unsigned long long)wall_clock64()
 #define RT_TL(...) __VA_ARGS__
 #else
@@ -475,6 +476,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
     st.sp = 0;
     RT_TL(unsigned long long tl_t0 = 0; uint32_t tl_ns = 0, tl_nl = 0, tl_ts = 0, tl_tlanes = 0;)
     RT_TL(unsigned long long tlt[6] = {0, 0, 0, 0, 0, 0};)
+    RT_TL(unsigned long long tlu[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0, u5 = 0, u6 = 0;)
     RT_TL(unsigned long long tlr_t0 = 0; uint32_t tlr_nodes = 0, tlr_leaves = 0, tlr_posts = 0, tlr_waits = 0, tlr_rounds = 0;)
     RT_TL(if (MODE == RT_TIMELINE) { const unsigned long long now = (unsigned long long)wall_clock64(); if (lane == 0) atomicMin(&g_tl_t0, now); tl_t0 = now; })
 
@@ -532,6 +534,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         // subtrees are taken, and cancellations seen, in every round — an owner must never wait on a task nobody takes)
         if (split_now || MEGA) {
             RT_CLK(s0);
+            RT_TL(u0 = (unsigned long long)wall_clock64();)
             // (a) an idle lane takes a posted subtree
             if (!alive && st.blk[1] != 0) {
                 const uint32_t start = (lane * 7u + st.slot + round) % st.n_board;
@@ -568,6 +571,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 }
             }
             RT_CLK(s1);
+            RT_TL(u1 = (unsigned long long)wall_clock64();)
             // (b) the wave tells the workgroup how many of its lanes are idle
             {
                 const uint32_t n_idle_now = split_now ? (uint32_t)__popcll(__ballot(!alive)) : 0u;
@@ -577,6 +581,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 }
             }
             RT_CLK(s2);
+            RT_TL(u2 = (unsigned long long)wall_clock64();)
             // (c) a busy lane posts the bottom-most entry of its mesh-level stack while idle lanes outnumber posted tasks
             RT_STAT(if (split_now && alive && in_mesh && !no_donate && don_next < st.sp) { st.acc->n_elig++; if (!(st.blk[2] > st.blk[1])) st.acc->n_gate++; })
             for (int pass = 0; pass < RT_DONATE_PASSES && split_now && alive && in_mesh && !no_donate && don_next < st.sp && st.blk[2] > st.blk[1] && st.blk[1] < st.n_board; pass++) {
@@ -613,6 +618,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                 }
             }
             RT_CLK(s3);
+            RT_TL(u3 = (unsigned long long)wall_clock64();)
             // The slots given away are the bottom of the mesh-level stack: close the gap (usually nothing is left
             // above it), so that the stack stays short and in LDS instead of growing into its global part.
             if (alive && in_mesh && don_next > don_base) {
@@ -632,6 +638,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     cur = st.pop(-1.0f, cur_t);              // everything above the sentinel is culled by a negative bound
                 }
             }
+            RT_TL(if (MODE == RT_TIMELINE && exhausted) { const unsigned long long u4_ = (unsigned long long)wall_clock64(); tlu[0] += u1 - u0; tlu[1] += u2 - u1; tlu[2] += u3 - u2; tlu[3] += u4_ - u3; })
             RT_STAT({ const unsigned long long s4 = wall_clock64(); if (__any(alive)) { st.acc->ts_a += s1 - s0; st.acc->ts_b += s2 - s1; st.acc->ts_c += s3 - s2; st.acc->ts_d += s4 - s3; } })
         }
 
@@ -969,6 +976,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         RT_TLC(q4);
         for (int tpass = 0;; tpass++) {
         RT_CLK(xa);
+        RT_TL(u4 = (unsigned long long)wall_clock64();)
         bool finished = fin;
         if (alive && !fin) do {
             if (!(cur & RT_LINK_LEAF)) break;          // still on an interior record (the node phase was left early)
@@ -995,6 +1003,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     }
                     // ---- replay the helpers' candidates in visiting order with the reference's rule
                     const uint32_t nc = st.cand_cnt[st.slot];
+                    RT_TL(if (MODE == RT_TIMELINE) { atomicAdd(&g_tl_tail2[6], 1ull); atomicAdd(&g_tl_tail2[7], (unsigned long long)nc); })
                     if (nc > RT_CAND_MAX) {
                         redo = true;                           // too many to keep: trace this mesh again, alone
                     } else {
@@ -1189,6 +1198,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             }
         } while (0);
         RT_CLK(xb);
+        RT_TL(u5 = (unsigned long long)wall_clock64();)
 
         if (alive && finished) {
             if (helper) {
@@ -1219,6 +1229,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         }
         if constexpr (MEGA) io.flush(lane, lanes_below);   // finished rays: hits to the shading wave, the others off the workgroup's count
         RT_CLK(xc);
+        RT_TL(if (MODE == RT_TIMELINE && exhausted) { u6 = (unsigned long long)wall_clock64(); tlu[4] += u5 - u4; tlu[5] += u6 - u5; })
         RT_STAT(st.acc->x_block += xb - xa; st.acc->x_retire += xc - xb; st.acc->x_passes++;)
         if (tpass >= RT_REFILL_PASSES || (exhausted && !MEGA)) break;
         // ---- refill idle lanes
@@ -1429,6 +1440,6 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
         RT_STAT({ if (exhausted) { const unsigned long long c5 = wall_clock64(); st.acc->tl_rounds++; st.acc->tl_sched += c1 - c0; st.acc->tl_node += c2 - c1; st.acc->tl_tri += c3 - c2; st.acc->tl_big += c4 - c3; st.acc->tl_trans += c5 - c4; } })
         RT_STAT({ const unsigned long long c5 = wall_clock64(); st.acc->t_sched += c1 - c0; st.acc->t_node += c2 - c1; st.acc->t_tri += c3 - c2; st.acc->t_big += c4 - c3; st.acc->t_trans += c5 - c4; })
     }
-    RT_TL(if (MODE == RT_TIMELINE && lane == 0) { for (int k_ = 0; k_ < 6; k_++) atomicAdd(&g_tl_tail[k_], tlt[k_]); })
+    RT_TL(if (MODE == RT_TIMELINE && lane == 0) { for (int k_ = 0; k_ < 6; k_++) atomicAdd(&g_tl_tail[k_], tlt[k_]); for (int k_ = 0; k_ < 6; k_++) atomicAdd(&g_tl_tail2[k_], tlu[k_]); })
 }
 #undef RT_ISANY
