@@ -71,10 +71,17 @@
 #define RT_MIN_WAVES 4           // __launch_bounds__ waves per SIMD for the trace kernels
 #endif
 #ifndef RT_REFILL_MIN
-#define RT_REFILL_MIN 16         // idle lanes of a wave that trigger a refill from the generation's cursor
+#define RT_REFILL_MIN 24         // idle lanes of a wave that trigger a refill from the generation's cursor (16 until the transitions got cheaper)
 #endif
 #ifndef RT_STRIP
 #define RT_STRIP 8               // closest-hit: consecutive items of a 64-item block handed out together (divides 64)
+#define RT_STRIP_LOG2 3
+#endif
+#ifndef RT_STRIP_WIDE_LOG2
+#define RT_STRIP_WIDE_LOG2 5     // ... 32 of them in launches of at least RT_WIDE_STRIP_BLOCKS blocks
+#endif
+#ifndef RT_WIDE_STRIP_BLOCKS
+#define RT_WIDE_STRIP_BLOCKS 100000
 #endif
 #ifndef RT_TRI_UNROLL
 #define RT_TRI_UNROLL 2          // triangles of a queued leaf a lane loads together
@@ -400,10 +407,14 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
     bool lane_any = ANY_ONLY;
 #define RT_ISANY (MIXED ? lane_any : ANY_ONLY)
     constexpr uint32_t QCAP = ANY_ONLY ? RT_LEAF_QUEUE_ANY : (NEAR ? RT_LEAF_QUEUE_NEAR : RT_LEAF_QUEUE);
-    constexpr uint32_t STRIP = ANY_ONLY ? RT_STRIP_ANY : RT_STRIP;
+    // (closest-hit items of a large launch go out in wider strips: with many blocks per wave the end of the launch balances
+    // itself, and 32 neighbours in a wave instead of 8 share more of their traversal — inst10 8K -2.8 %, mesh1m 4K -0.5 %; on
+    // a 1080p launch, 8 blocks per wave, the same strips cost 3 %)
+    const uint32_t strip_shift_ = ANY_ONLY ? 6u : ((end - begin + 63u) / 64u >= (uint32_t)RT_WIDE_STRIP_BLOCKS ? (uint32_t)RT_STRIP_WIDE_LOG2 : (uint32_t)RT_STRIP_LOG2);
+    const uint32_t STRIP = 1u << strip_shift_;
     constexpr uint32_t REFILL_MIN = ANY_ONLY ? RT_REFILL_MIN_ANY : RT_REFILL_MIN;
     constexpr uint32_t EXIT_FEW = ANY_ONLY ? RT_EXIT_FEW_ANY : RT_EXIT_FEW, EXIT_WAIT = ANY_ONLY ? RT_EXIT_WAIT_ANY : RT_EXIT_WAIT;
-    static_assert(64 % STRIP == 0, "strips tile a 64-item block");
+    static_assert(RT_STRIP_ANY == 64 && (1 << RT_STRIP_LOG2) == RT_STRIP && RT_STRIP_WIDE_LOG2 <= 6, "strips tile a 64-item block");
     static_assert(RT_LEAF_QUEUE_ANY <= RT_LEAF_QUEUE, "the LDS queue is sized by RT_LEAF_QUEUE");
     const uint32_t lane = st.lane;
     const uint64_t lanes_below = (1ull << lane) - 1ull;
@@ -1276,7 +1287,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     if (!alive && rank >= n_ring && rank < n_idle) {
                         const uint32_t c = base + (rank - n_ring);
                         if (c < p_padded) {
-                            const uint32_t strip = c / STRIP, within = c % STRIP;
+                            const uint32_t strip = c >> strip_shift_, within = c & (STRIP - 1u);
                             const uint32_t i = begin + (pb0 + strip % pnb) * 64u + (strip / pnb) * STRIP + within;
                             if (i < end) { valid = true; it = i; }
                         }
@@ -1376,7 +1387,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                             // items block by block (item ids: the first kind's padded count, then the second kind) —
                             // the cheap any-hit rays are what is in flight when the cursor runs dry
                             if (c < pc_n * 64u) {
-                                const uint32_t strip = c / STRIP, within = c % STRIP;
+                                const uint32_t strip = c >> strip_shift_, within = c & (STRIP - 1u);
                                 i = (pb0 + strip % pc_n) * 64u + (strip / pc_n) * STRIP + within;
                                 valid = i < io.first_count();
                             } else {
@@ -1385,7 +1396,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                             }
                             i += begin;
                         } else {
-                            const uint32_t strip = c / STRIP, within = c % STRIP;
+                            const uint32_t strip = c >> strip_shift_, within = c & (STRIP - 1u);
                             i = begin + (pb0 + strip % pnb) * 64u + (strip / pnb) * STRIP + within;
                             valid = i < end;
                         }
