@@ -134,6 +134,9 @@
 #ifndef RT_EARLY_FINISH
 #define RT_EARLY_FINISH 1        // a ray whose stack runs empty in the transition pass is retired in that pass
 #endif
+#ifndef RT_NODE_RUN
+#define RT_NODE_RUN 1            // top-level walk: the nodes up to the next prim are taken in a loop of their own (0: one item per turn, node or prim)
+#endif
 #ifndef RT_FLAT_TOP
 #define RT_FLAT_TOP 1            // the top level is walked in the transition block, item by item (rt_device.h: RT_TOPITEM_*); 0: as 4-wide records in the node phase
 #endif
@@ -1100,6 +1103,22 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
             // records in the node phase, every top-level leaf cost the ray a round of its wave.)
             while (top_slot < S.n_top_items) {
                 RT_STAT({ st.acc->y_liters++; if ((int)lane == __ffsll((unsigned long long)__ballot(1)) - 1) st.acc->y_witers++; })
+#if RT_NODE_RUN
+                // (the nodes up to the next prim in a loop of their own: the lanes of a wave then meet at the prims, whose
+                // branch is the long one, instead of running it in every turn in which one of them has a prim)
+                uint4 it0 = S.top_items[2u * top_slot], it1 = S.top_items[2u * top_slot + 1u];
+                while (it1.w == RT_TOPITEM_NODE) {
+                    float te_;
+                    const bool hit_ = box_test(ar, __uint_as_float(it0.x), __uint_as_float(it0.y), __uint_as_float(it0.z), __uint_as_float(it0.w),
+                                               __uint_as_float(it1.x), __uint_as_float(it1.y), minT, te_);
+                    top_slot = hit_ ? top_slot + 1u : it1.z;
+                    if (top_slot >= S.n_top_items) break;
+                    it0 = S.top_items[2u * top_slot];
+                    it1 = S.top_items[2u * top_slot + 1u];
+                }
+                if (top_slot >= S.n_top_items) break;
+                top_slot++;
+#else
                 const uint4 it0 = S.top_items[2u * top_slot], it1 = S.top_items[2u * top_slot + 1u];
                 if (it1.w == RT_TOPITEM_NODE) {
                     float te_;
@@ -1109,6 +1128,7 @@ __device__ void trace_persistent(const DScene& S, IO& io, uint32_t begin, uint32
                     continue;
                 }
                 top_slot++;
+#endif
                 DTopPrim tp;
                 tp.kind = it0.x; tp.index = it0.y; tp.obj = it0.z; tp.remaining = 0;
 #else
